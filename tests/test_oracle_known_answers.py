@@ -1,0 +1,143 @@
+"""CPU oracle vs the known answers of the reference's own gtest files
+(cpp_impl/suriko-test/test-bundle-adj-kanatani.cpp, test-obs-geom.cpp, test-eigen-helpers.cpp)."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_normalization_simple(orc):
+    """test-bundle-adj-kanatani.cpp:22-128 NormalizationSimple."""
+    atol = 1e-2
+    pts = np.array([[-1, 0, 0], [-0.5, 0.866, 0], [0, 1, 0], [1, 0, 0], [0, -1, 0]], dtype=np.float64)
+    R, T = orc.circle_camera_shots([0, 0, 0], 1.0, 0.0, [3 * math.pi / 2 + math.pi / 6, 3 * math.pi / 2])
+    K = np.eye(3).reshape(1, 9)
+    sc = orc.Scene(pts, R, T, K, 1, np.arange(6), np.zeros(5, dtype=np.int32), np.zeros((5, 2)))
+    before = sc.copy()
+    ok, nrm = orc.normalize(sc, t1y=1.0, comp=0)
+    assert ok
+    assert np.linalg.norm(sc.cam_T[0]) < atol
+    assert np.abs(sc.cam_R[0].reshape(3, 3) - np.eye(3)).max() < atol
+    R1 = sc.cam_R[1].reshape(3, 3)
+    t10 = -R1.T @ sc.cam_T[1]
+    assert abs(abs(t10[0]) - 1.0) < 0.01
+    s = nrm.world_scale
+    cam0 = np.array([[-0.866, 0, 1.5], [0, 0, 2], [0.5, 0, 1.866], [0.866, 0, 0.5], [-0.5, 0, 0.133975]]) * s
+    for e, a in zip(cam0, sc.points):
+        assert np.linalg.norm(e - a) < atol
+    cam1 = np.array([[-1, 0, 1], [-0.5, 0, 1.866], [0, 0, 2], [1, 0, 1], [0, 0, 0]], dtype=np.float64) * s
+    for e, x in zip(cam1, sc.points):
+        assert np.linalg.norm(e - (R1 @ x + sc.cam_T[1])) < atol
+    orc.revert(sc, nrm)
+    assert np.abs(sc.cam_T - before.cam_T).max() < atol
+    assert np.abs(sc.cam_R - before.cam_R).max() < atol
+    assert np.abs(sc.points - before.points).max() < atol
+
+
+def test_normalization_fails_on_zero_shift(orc):
+    """bundle-adj-kanatani.cpp:215-217: zero T01 component -> false."""
+    R = np.tile(np.eye(3).reshape(1, 9), (2, 1))
+    T = np.array([[0, 0, 0], [1.0, 0, 0]])
+    sc = orc.Scene(np.zeros((1, 3)), R, T, np.eye(3).reshape(1, 9), 1, [0, 1], [0], np.zeros((1, 2)))
+    ok, _ = orc.normalize(sc, comp=1)
+    assert not ok
+    ok, _ = orc.normalize(sc, comp=0)
+    assert ok
+
+
+def test_skew(orc):
+    """test-obs-geom.cpp:18-27."""
+    S = orc.skew([1, 2, 3])
+    assert S[0, 0] == 0 and S[0, 1] == -3 and S[1, 0] == 3
+
+
+def test_rodrigues_120(orc):
+    """test-obs-geom.cpp:29-44: 120 deg about (1,1,1) maps (10,0,0) to (0,10,0)."""
+    d = np.ones(3) * (2 * math.pi / 3) / math.sqrt(3)
+    ok, R = orc.rot_from_axis_angle(d)
+    assert ok
+    v = R @ np.array([10.0, 0, 0])
+    assert abs(v[0]) < 1e-5 and abs(v[1] - 10) < 1e-5 and abs(v[2]) < 1e-5
+
+
+def test_axis_angle_round_trip(orc):
+    """test-obs-geom.cpp:46-62."""
+    d = np.ones(3) * (math.pi / 4) / math.sqrt(3)
+    ok, R = orc.rot_from_axis_angle(d)
+    assert ok
+    ok, back = orc.axis_angle_from_rot(R)
+    assert ok and np.abs(back - d).max() < 1e-5
+
+
+def test_axis_angle_corner_cases(orc):
+    """test-obs-geom.cpp:64-81."""
+    ok, _ = orc.rot_from_axis_angle([0, 0, 0])
+    assert not ok
+    ok, _ = orc.rot_from_unity_dir_and_angle([0, 0, 0], 100.0)
+    assert not ok
+    ok, _ = orc.rot_from_unity_dir_and_angle([1, 1, 1], 0.0)
+    assert not ok
+
+
+REMOVE_CASES = [
+    # (matrix, rows, cols, expected)  test-eigen-helpers.cpp:16-190
+    ([[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]], [1], [2], [[1, 2, 4], [9, 10, 12]]),
+    ([[1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [11, 12, 13, 14, 15], [16, 17, 18, 19, 20]], [1, 2], [1, 2, 4], [[1, 4], [16, 19]]),
+    ([[1, 2, 3], [4, 5, 6]], [], [1], [[1, 3], [4, 6]]),
+    ([[1, 2], [3, 4], [5, 6]], [1], [], [[1, 2], [5, 6]]),
+    ([[1, 2, 3, 4], [5, 6, 7, 8]], [], [0, 1], [[3, 4], [7, 8]]),
+    ([[1, 2, 3, 4], [5, 6, 7, 8]], [], [2, 3], [[1, 2], [5, 6]]),
+    ([[1, 2], [3, 4], [5, 6], [7, 8]], [0, 1], [], [[5, 6], [7, 8]]),
+    ([[1, 2], [3, 4], [5, 6], [7, 8]], [2, 3], [], [[1, 2], [3, 4]]),
+    ([[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]], [0, 2], [0, 3], [[6, 7]]),
+    ([[1, 2], [3, 4]], [], [], [[1, 2], [3, 4]]),
+]
+
+
+@pytest.mark.parametrize("mat,rows,cols,expect", REMOVE_CASES)
+def test_remove_rows_cols(orc, mat, rows, cols, expect):
+    out = orc.remove_rows_cols(np.array(mat), rows, cols)
+    assert np.array_equal(out, np.array(expect))
+
+
+@pytest.mark.parametrize("rows,cols", [([0, 1], []), ([], [0, 1]), ([0, 1], [0, 1])])
+def test_remove_all(orc, rows, cols):
+    """test-eigen-helpers.cpp:165-190 RemoveAll -> empty matrix."""
+    out = orc.remove_rows_cols(np.array([[1, 2], [3, 4]]), rows, cols)
+    assert out.size == 0
+
+
+def test_householder_qr(orc):
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 5, 37):
+        A = rng.randn(n, n) + n * np.eye(n)
+        b = rng.randn(n)
+        ok, x = orc.householder_qr_solve(A, b)
+        assert ok
+        assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-11
+    ok, x = orc.householder_qr_solve(np.zeros((3, 3)), np.ones(3))
+    assert not ok  # singular -> non finite -> reference returns false (:1912-1913)
+
+
+def test_inverse3x3(orc):
+    rng = np.random.RandomState(1)
+    A = rng.randn(3, 3)
+    A = A @ A.T + np.eye(3)
+    ok, Ai, det = orc.inverse3x3(A)
+    assert ok and np.abs(Ai - np.linalg.inv(A)).max() < 1e-12
+    assert det == pytest.approx(np.linalg.det(A), rel=1e-12)
+    ok, _, det = orc.inverse3x3(np.diag([1.0, 1.0, 1e-13]))  # |det| <= 1e-12 -> not invertible
+    assert not ok
+    ok, _, _ = orc.inverse3x3(np.diag([1.0, 1.0, 1e-11]))
+    assert ok
+
+
+def test_is_close_quirk(orc):
+    """approx-alg.h:8-16: tolerance uses |max(a,b)|, not max(|a|,|b|)."""
+    lib = orc.lib()
+    import ctypes as C
+    f = lib.orc_is_close
+    f.argtypes = [C.c_double] * 4
+    assert f(0.0, 1e-9, 1e-5, 1e-8)
+    assert not f(0.0, -2e-8, 1e-5, 1e-8)      # max(0,-2e-8)=0 -> only atol
+    assert f(100.0, 100.0005, 1e-5, 1e-8)
