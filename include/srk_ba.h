@@ -1,0 +1,198 @@
+/*
+ * srk_ba.h -- C ABI of the MI355X-native bundle-adjustment core (libsrk_ba.so).
+ *
+ * Drop-in boundary for whigg/surikatoko's BundleAdjustmentKanatani
+ * (cpp_impl/suriko-engine/include/suriko/bundle-adj-kanatani.h:165-193).  The reference has no
+ * FFI layer: its boundary is the C++ class API.  These entry points are what a thin adapter with
+ * that class's signature binds (see include/suriko_amd/bundle-adj-kanatani.hpp and INTEGRATION.md):
+ *
+ *   reference (file:line)                                       C ABI
+ *   ----------------------------------------------------------  ------------------------------------
+ *   BundleAdjustmentKanatani::ComputeInplace  .h:179-184        srk_ba_compute_inplace
+ *   BundleAdjustmentKanatani::ReprojError     .h:167-172        srk_ba_reproj_error
+ *   ...::OptimizationStatusString             .h:193            srk_ba_status_string
+ *   NormalizeSceneInplace / SceneNormalizer   .h:16-62          srk_ba_normalize_scene / srk_ba_revert_normalization
+ *   CheckWorldIsNormalized                    .h:64-65          srk_ba_check_world_is_normalized
+ *   BundleAdjustmentKanataniTermCriteria      .h:68-92          the two optional-double pointers
+ *
+ * Flat, caller-owned, row-major doubles; no exceptions cross the ABI; one srk_ba per thread/GPU.
+ *   points      [N][3]   world coordinates, index = pnt_ind (order of reconstructed tracks, .cpp:1161-1169)
+ *   cam_R,cam_T [M][9],[M][3]  world->camera ("inverse orientation", as on the reference API)
+ *   K           [M][9] or [1][9] when shared_k != 0 (exactly one of shared_K / Ks in the reference, .cpp:421)
+ *   obs_row_ptr [N+1] int64; obs_frame [O] int32 strictly ascending inside a point; obs_uv [O][2] pixels
+ * Per-frame variable order [fx fy u0 v0 Tx Ty Tz Wx Wy Wz] (bundle-adj-kanatani.h:113-118).
+ *
+ * Return convention of the optimisation calls: 0 = optimised (reference `true`), 1 = not optimised
+ * (reference `false`, see report.status), negative = SRK_E_* argument / device error.
+ */
+#ifndef SRK_BA_H
+#define SRK_BA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srk_ba srk_ba; /* opaque: owns device buffers, stream, events */
+
+enum srk_status {
+    SRK_STATUS_NONE = 0,               /* "" : normalisation failed (.cpp:681-682) or not run */
+    SRK_STATUS_ABS_ERR_THRESHOLD = 1,  /* "abs err threshold"           -> true  (.cpp:749-753) */
+    SRK_STATUS_SMALL_ERR_CHANGE = 2,   /* "small relative err change"   -> true  (.cpp:880-884) */
+    SRK_STATUS_HESSIAN_OVERFLOW = 3,   /* "hessian overflow"            -> false (.cpp:843-847,866) */
+    SRK_STATUS_ERR_CONVERGED = 4,      /* "err converged to limit value"-> false (.cpp:828-838,868) */
+    SRK_STATUS_MAX_ITERATIONS = 5,     /* harness addition (the reference has no cap, .cpp:756) */
+    SRK_STATUS_DEVICE_ERROR = 6        /* "device error" */
+};
+
+enum srk_error {
+    SRK_OK = 0,
+    SRK_E_ARGS = -1,     /* bad argument (f0 ~ 0, M < 2, NULL arrays, unsorted frames, ...) */
+    SRK_E_DEVICE = -2,   /* HIP error, see srk_ba_last_error */
+    SRK_E_STATE = -3,    /* staged call without an uploaded scene */
+    SRK_E_NOMEM = -4
+};
+
+typedef struct srk_ba_report {
+    int32_t status;          /* enum srk_status */
+    int32_t optimized;       /* reference bool */
+    int64_t iterations;      /* accepted outer LM iterations (.cpp:756-891) */
+    int64_t attempts;        /* solve+apply+error attempts (.cpp:775-850) */
+    int64_t seen;            /* observation count over all ranks (.cpp:483) */
+    double err_initial;      /* (pix/f0)^2 units */
+    double err_final;
+    double hessian_factor;   /* value at exit */
+    double world_scale;      /* SceneNormalizer::WorldScale */
+    /* device time per phase, milliseconds, summed over the call (hipEvent pairs) */
+    double ms_jacobian;      /* residuals + all normal-equation blocks (.cpp:1140-1448) */
+    double ms_schur;         /* reduced camera system build (.cpp:1780-1908) */
+    double ms_solve;         /* dense factor + solve (.cpp:1911) */
+    double ms_backsub;       /* point back-substitution (.cpp:1919-1960) */
+    double ms_apply;         /* apply corrections (.cpp:1997-2063) */
+    double ms_error;         /* reprojection error (.cpp:410-490) */
+    double ms_total;         /* wall time of the optimise call */
+    int64_t schur_launches, jacobian_launches; /* kernel launches of the two HBM-bound phases */
+    double ms_jacobian_kernel; /* time of the point-major Jacobian kernel alone (roofline numerator) */
+    double ms_solve_syrk;      /* time inside the MFMA trailing-update kernels of the dense solve */
+} srk_ba_report;
+
+typedef struct srk_ba_normalizer {
+    double R0[9], T0[3];   /* cam0 before normalisation (SceneNormalizer::prenorm_cam0_from_world) */
+    double world_scale;
+} srk_ba_normalizer;
+
+/* ---- lifetime ---- */
+srk_ba* srk_ba_create(int device_id);            /* NULL on failure (no HIP device, bad id) */
+void srk_ba_destroy(srk_ba*);
+const char* srk_ba_last_error(const srk_ba*);    /* text of the last SRK_E_DEVICE / SRK_E_ARGS */
+const char* srk_ba_status_string(int status);    /* the four reference strings (+ harness additions) */
+int srk_ba_device_count(void);                   /* HIP devices visible; 0 when none */
+/* run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the handle's own */
+int srk_ba_set_stream(srk_ba*, void* hip_stream);
+
+/* ---- multi-GPU (landmark sharding) ----
+ * Every rank owns a contiguous pnt_ind range and passes only that range to the scene calls; cameras
+ * are replicated.  The three exchange steps (frame blocks once per outer iteration; reduced camera
+ * system + rhs once per attempt; error scalar) call `fn` to sum `count` doubles in place across ranks.
+ * `dev_ptr` is device memory on the handle's stream; the hook must return after the reduction is
+ * ordered on that stream (or complete).  Returns 0 on success. */
+typedef int (*srk_allreduce_fn)(void* ctx, double* dev_ptr, int64_t count);
+int srk_ba_set_allreduce(srk_ba*, srk_allreduce_fn fn, void* ctx, int rank, int world_size);
+
+/* ---- the reference API, one call ---- */
+int srk_ba_compute_inplace(srk_ba*, double f0,
+                           int64_t n_points, double* points_xyz,
+                           int32_t n_frames, double* cam_R, double* cam_T,
+                           const double* K, int shared_k,
+                           const int64_t* obs_row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                           const double* allowed_err_change /* NULL = unset */,
+                           const double* max_hessian_factor /* NULL = unset */,
+                           int64_t max_iterations /* <= 0 = unlimited (reference behaviour) */,
+                           srk_ba_report* out);
+
+double srk_ba_reproj_error(srk_ba*, double f0,
+                           int64_t n_points, const double* points_xyz,
+                           int32_t n_frames, const double* cam_R, const double* cam_T,
+                           const double* K, int shared_k,
+                           const int64_t* obs_row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                           int64_t* seen /* may be NULL */); /* NaN on error */
+
+/* host-side gauge normalisation (bundle-adj-kanatani.cpp:203-270); no GPU needed */
+int srk_ba_normalize_scene(int64_t n_points, double* points_xyz, int32_t n_frames, double* cam_R, double* cam_T,
+                           double t1y, int32_t unity_comp_ind, srk_ba_normalizer* out); /* 1 = ok, 0 = failed */
+void srk_ba_revert_normalization(int64_t n_points, double* points_xyz, int32_t n_frames, double* cam_R,
+                                 double* cam_T, const srk_ba_normalizer* nrm);
+int srk_ba_check_world_is_normalized(int32_t n_frames, const double* cam_R, const double* cam_T, double t1y,
+                                     int32_t unity_comp_ind);
+
+/* ---- staged API: scene resident in HBM (bench, parity tests, repeated solves) ----
+ * upload = gauge-normalise on the host (unless already_normalized) + copy to the device;
+ * optimize = the device-resident LM loop (.cpp:720-893); download = copy back + revert normalisation. */
+int srk_ba_upload_scene(srk_ba*, double f0,
+                        int64_t n_points, const double* points_xyz,
+                        int32_t n_frames, const double* cam_R, const double* cam_T,
+                        const double* K, int shared_k,
+                        const int64_t* obs_row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                        int already_normalized);
+int srk_ba_optimize(srk_ba*, const double* allowed_err_change, const double* max_hessian_factor,
+                    int64_t max_iterations, srk_ba_report* out);
+int srk_ba_download_scene(srk_ba*, double* points_xyz, double* cam_R, double* cam_T, int revert_normalization);
+/* restore the scene that was uploaded (device-side copy), so that a bench can repeat identical steps */
+int srk_ba_reset_scene(srk_ba*);
+
+/* single phases on the resident scene (parity tests and per-kernel timing) */
+int srk_ba_phase_error(srk_ba*, double* err, int64_t* seen);
+int srk_ba_phase_derivatives(srk_ba*);
+int srk_ba_phase_schur(srk_ba*, double hessian_factor);
+int srk_ba_phase_solve(srk_ba*);                            /* 0 ok, 1 non-finite / not positive definite */
+int srk_ba_phase_backsub(srk_ba*, double hessian_factor);   /* also forms the trial scene (apply) */
+int srk_ba_phase_accept(srk_ba*);                           /* trial scene becomes current */
+
+/* copies of device buffers for the parity tests, expanded to the oracle's layouts */
+enum srk_buffer {
+    SRK_BUF_GRAD = 0,        /* [3N + 10M] gradE */
+    SRK_BUF_POINT_BLOCKS,    /* [N][3][3] */
+    SRK_BUF_FRAME_BLOCKS,    /* [M][10][10] */
+    SRK_BUF_POINT_FRAME,     /* [O][3][10] */
+    SRK_BUF_RCS,             /* [10M][10M] padded reduced camera system (fixed variables: identity rows) */
+    SRK_BUF_RCS_RHS,         /* [10M] */
+    SRK_BUF_CORRECTIONS,     /* [3N + 10M] corrections with zero gaps */
+    SRK_BUF_POINTS,          /* [N][3] current (normalised) points */
+    SRK_BUF_CAM_R,           /* [M][9] */
+    SRK_BUF_CAM_T            /* [M][3] */
+};
+int64_t srk_ba_buffer_size(srk_ba*, int which);                 /* doubles; negative on error */
+int srk_ba_download(srk_ba*, int which, double* dst, int64_t count);
+
+/* bench knob: record event pairs around every MFMA trailing-update launch (fills report.ms_solve_syrk) */
+int srk_ba_set_profile(srk_ba*, int profile_syrk);
+
+/* dense SPD solve A x = b on the device (the reduced-camera-system solver on its own; A row-major
+ * n x n, lower triangle read).  returns 0 ok, 1 not positive definite, negative on error. */
+int srk_ba_dense_spd_solve(srk_ba*, int64_t n, const double* A, const double* b, double* x, double* ms_factor);
+
+/* ---- synthetic scenes (host; restates demos/demo-bundle-adj-circle-grid.cpp:86-257 and
+ * src/virt-world/scene-generator.cpp:9-55, with the visibility window of SURVEY 8d) ---- */
+typedef struct srk_scene_spec {
+    int32_t n_frames;        /* M */
+    int32_t grid_nx, grid_ny;/* N = nx * ny */
+    int32_t vis_window;      /* L consecutive frames per point; <= 0 or >= M: every frame (the demo) */
+    double half_extent_x, half_extent_y; /* points on [-hx,hx] x [-hy,hy] */
+    double f0;               /* 600 */
+    double noise_x3d_hi;     /* 0.005 */
+    double noise_r_hi;       /* 0.005 */
+    double noise_uv_pix;     /* 0 (the demo projects exactly) */
+    uint32_t seed;           /* 1234 */
+} srk_scene_spec;
+int64_t srk_scene_num_observations(const srk_scene_spec*);
+/* fills caller arrays: points [N][3] (noisy), points_gt [N][3] (may be NULL), cam_R/T [M][..] (noisy),
+ * cam_R_gt/cam_T_gt (may be NULL), K [M][9], row_ptr [N+1], obs_frame [O], obs_uv [O][2] */
+int srk_scene_generate(const srk_scene_spec*, double* points, double* points_gt, double* cam_R, double* cam_T,
+                       double* cam_R_gt, double* cam_T_gt, double* K, int64_t* row_ptr, int32_t* obs_frame,
+                       double* obs_uv);
+void srk_circle_camera_shots(const double center[3], double radius, double ascent_z, int32_t n,
+                             const double* angles, double* cam_R, double* cam_T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

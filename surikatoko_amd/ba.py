@@ -1,0 +1,307 @@
+"""Host-side mirror of the reference's BA operator interface over the C ABI (include/srk_ba.h).
+
+Same names, argument meaning and error behaviour as suriko's
+  BundleAdjustmentKanatani            cpp_impl/suriko-engine/include/suriko/bundle-adj-kanatani.h:96-261
+  BundleAdjustmentKanataniTermCriteria                                             .h:68-92
+  NormalizeSceneInplace / CheckWorldIsNormalized                                   .h:61-65
+so that tests/ read like the reference's own tests.  Scenes are flat arrays (class Scene) instead of
+FragmentMap / CornerTrackRepository / std::vector<SE3Transform>; the C++ adapter that converts those
+containers is include/suriko_amd/bundle-adj-kanatani.hpp.
+
+Everything computes on the GPU through libsrk_ba.so.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from ._lib import Normalizer, Report, lib
+
+BUF_GRAD, BUF_POINT_BLOCKS, BUF_FRAME_BLOCKS, BUF_POINT_FRAME, BUF_RCS, BUF_RCS_RHS, BUF_CORRECTIONS, BUF_POINTS, \
+    BUF_CAM_R, BUF_CAM_T = range(10)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def status_string(status):
+    return lib().srk_ba_status_string(int(status)).decode()
+
+
+def device_count():
+    return int(lib().srk_ba_device_count())
+
+
+class Scene:
+    """Flat scene arrays in the C-ABI layout (include/srk_ba.h); arrays are owned copies, mutated in place by BA."""
+
+    def __init__(self, points, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv):
+        self.points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3).copy()
+        self.cam_R = np.ascontiguousarray(cam_R, dtype=np.float64).reshape(-1, 9).copy()
+        self.cam_T = np.ascontiguousarray(cam_T, dtype=np.float64).reshape(-1, 3).copy()
+        self.K = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 9).copy()
+        self.shared_k = int(bool(shared_k))
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64).copy()
+        self.obs_frame = np.ascontiguousarray(obs_frame, dtype=np.int32).copy()
+        self.obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2).copy()
+
+    N = property(lambda self: self.points.shape[0])
+    M = property(lambda self: self.cam_R.shape[0])
+    O = property(lambda self: int(self.row_ptr[-1]))
+
+    def copy(self):
+        return Scene(self.points, self.cam_R, self.cam_T, self.K, self.shared_k, self.row_ptr, self.obs_frame,
+                     self.obs_uv)
+
+    def shard(self, rank, world):
+        """Landmark shard of this scene for `rank` of `world` (contiguous pnt_ind range balanced by observation
+        count, cameras replicated) -- SURVEY 8e partitioning."""
+        lo, hi = shard_bounds(self.row_ptr, rank, world)
+        o0, o1 = int(self.row_ptr[lo]), int(self.row_ptr[hi])
+        return Scene(self.points[lo:hi], self.cam_R, self.cam_T, self.K, self.shared_k,
+                     self.row_ptr[lo:hi + 1] - o0, self.obs_frame[o0:o1], self.obs_uv[o0:o1]), (lo, hi)
+
+    def scene_args(self):
+        return (C.c_int64(self.N), _p(self.points), C.c_int32(self.M), _p(self.cam_R), _p(self.cam_T), _p(self.K),
+                C.c_int(self.shared_k), _p(self.row_ptr), _p(self.obs_frame), _p(self.obs_uv))
+
+
+def shard_bounds(row_ptr, rank, world):
+    """Contiguous pnt_ind range [lo, hi) of `rank`: cut points chosen so every rank gets ~O/world observations."""
+    row_ptr = np.asarray(row_ptr)
+    N = len(row_ptr) - 1
+    O = int(row_ptr[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = O * r // world
+        cuts.append(int(np.searchsorted(row_ptr, target, side="left")))
+    cuts.append(N)
+    cuts = [min(max(c, 0), N) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+class BundleAdjustmentKanataniTermCriteria:
+    """bundle-adj-kanatani.h:68-92 -- two optionals; None = unset ('potentially optimize forever')."""
+
+    def __init__(self):
+        self._allowed_reproj_err_rel_change = None
+        self._max_hessian_factor = None
+
+    def AllowedReprojErrRelativeChange(self, value="__get__"):
+        if value == "__get__":
+            return self._allowed_reproj_err_rel_change
+        self._allowed_reproj_err_rel_change = value
+
+    def MaxHessianFactor(self, value="__get__"):
+        if value == "__get__":
+            return self._max_hessian_factor
+        self._max_hessian_factor = value
+
+
+def normalize_scene_inplace(scene, t1y_dist=1.0, unity_comp_ind=1):
+    """NormalizeSceneInplace (bundle-adj-kanatani.h:61-62, .cpp:277-286).  Returns (success, normalizer)."""
+    if not (0 <= unity_comp_ind < 3):
+        raise ValueError("Can normalize only one of [T1x, T1y, Tz] components")  # CHECK at .cpp:129
+    nrm = Normalizer()
+    ok = lib().srk_ba_normalize_scene(C.c_int64(scene.N), _p(scene.points), C.c_int32(scene.M), _p(scene.cam_R),
+                                      _p(scene.cam_T), C.c_double(t1y_dist), C.c_int32(unity_comp_ind), C.byref(nrm))
+    return bool(ok), nrm
+
+
+def revert_normalization(scene, nrm):
+    """SceneNormalizer::RevertNormalization (.cpp:249-270)."""
+    lib().srk_ba_revert_normalization(C.c_int64(scene.N), _p(scene.points), C.c_int32(scene.M), _p(scene.cam_R),
+                                      _p(scene.cam_T), C.byref(nrm))
+
+
+def check_world_is_normalized(scene, t1y=1.0, unity_comp_ind=1):
+    """CheckWorldIsNormalized (.cpp:288-333)."""
+    return bool(lib().srk_ba_check_world_is_normalized(C.c_int32(scene.M), _p(scene.cam_R), _p(scene.cam_T),
+                                                        C.c_double(t1y), C.c_int32(unity_comp_ind)))
+
+
+class BundleAdjustmentKanatani:
+    """Mirror of suriko::BundleAdjustmentKanatani on top of one srk_ba handle (one GPU)."""
+
+    kPointVarsCount = 3
+    kIntrinsicVarsCount = 4
+    kTVarsCount = 3
+    kWVarsCount = 3
+    kMaxFrameVarsCount = 10
+
+    def __init__(self, device=0):
+        self._lib = lib()
+        self._h = self._lib.srk_ba_create(int(device))
+        if not self._h:
+            raise RuntimeError("srk_ba_create failed: no usable HIP device (there is no CPU fallback)")
+        self._f0 = 0.0
+        self._scene = None
+        self._status = ""
+        self.report = Report()
+        self._hook = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.srk_ba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API
+    def ComputeInplace(self, f0, scene, term_crit=None, max_iterations=0):
+        """bool ComputeInplace(f0, map, inverse_orient_cams, track_rep, shared_K | Ks, term_crit)
+        (bundle-adj-kanatani.h:179-184).  `scene` is updated in place.  Raises ValueError where the reference
+        CHECK-aborts (f0 ~ 0; fewer than two frames)."""
+        a, m = self._criteria(term_crit)
+        self._f0 = float(f0)
+        self._scene = scene
+        self.report = Report()
+        rc = self._lib.srk_ba_compute_inplace(C.c_void_p(self._h), C.c_double(f0), *scene.scene_args(), a, m,
+                                              C.c_int64(max_iterations), C.byref(self.report))
+        self._raise(rc)
+        self._status = status_string(self.report.status)
+        return rc == 0
+
+    def ReprojError(self, f0, scene):
+        """static Scalar ReprojError(...) (.h:167-172, .cpp:410-490) -> (err, seen_points_count)."""
+        seen = C.c_int64(0)
+        e = self._lib.srk_ba_reproj_error(C.c_void_p(self._h), C.c_double(f0), *scene.scene_args(), C.byref(seen))
+        if math.isnan(e):
+            raise RuntimeError("srk_ba_reproj_error: " + self.last_error())
+        self._f0 = float(f0)
+        return float(e), int(seen.value)
+
+    def ReprojErrorPixPerPoint(self, reproj_err, seen_points_count):
+        """f0 * sqrt(err / seen) (.cpp:602-615)."""
+        return self._f0 * math.sqrt(reproj_err / float(seen_points_count))
+
+    def OptimizationStatusString(self):
+        return self._status
+
+    def PointsCount(self):
+        return self._scene.N
+
+    def FramesCount(self):
+        return self._scene.M
+
+    def VarsCount(self):
+        return 3 * self._scene.N + 10 * self._scene.M
+
+    def NormalizedVarsCount(self):
+        return self.VarsCount() - 7
+
+    # ---- staged API (resident scene)
+    def upload(self, f0, scene, already_normalized=False):
+        self._f0 = float(f0)
+        self._scene = scene
+        rc = self._lib.srk_ba_upload_scene(C.c_void_p(self._h), C.c_double(f0), *scene.scene_args(),
+                                           C.c_int(int(already_normalized)))
+        if rc == 1:
+            return False
+        self._raise(rc)
+        return True
+
+    def optimize(self, term_crit=None, max_iterations=0):
+        a, m = self._criteria(term_crit)
+        self.report = Report()
+        rc = self._lib.srk_ba_optimize(C.c_void_p(self._h), a, m, C.c_int64(max_iterations), C.byref(self.report))
+        self._raise(rc)
+        self._status = status_string(self.report.status)
+        return rc == 0
+
+    def download(self, scene=None, revert_normalization=True):
+        scene = scene or self._scene
+        self._raise(self._lib.srk_ba_download_scene(C.c_void_p(self._h), _p(scene.points), _p(scene.cam_R),
+                                                    _p(scene.cam_T), C.c_int(int(revert_normalization))))
+        return scene
+
+    def reset(self):
+        self._raise(self._lib.srk_ba_reset_scene(C.c_void_p(self._h)))
+
+    def set_profile(self, on=True):
+        self._raise(self._lib.srk_ba_set_profile(C.c_void_p(self._h), C.c_int(int(on))))
+
+    def set_stream(self, hip_stream_handle):
+        self._raise(self._lib.srk_ba_set_stream(C.c_void_p(self._h), C.c_void_p(hip_stream_handle)))
+
+    def set_allreduce(self, hook, rank, world):
+        """hook: an ALLREDUCE_FN instance (see surikatoko_amd/dist.py); kept alive by this object."""
+        self._hook = hook
+        self._raise(self._lib.srk_ba_set_allreduce(C.c_void_p(self._h), hook, None, int(rank), int(world)))
+
+    def phase_error(self):
+        e, seen = C.c_double(0), C.c_int64(0)
+        self._raise(self._lib.srk_ba_phase_error(C.c_void_p(self._h), C.byref(e), C.byref(seen)))
+        return e.value, seen.value
+
+    def phase_derivatives(self):
+        self._raise(self._lib.srk_ba_phase_derivatives(C.c_void_p(self._h)))
+
+    def phase_schur(self, hessian_factor):
+        self._raise(self._lib.srk_ba_phase_schur(C.c_void_p(self._h), C.c_double(hessian_factor)))
+
+    def phase_solve(self):
+        rc = self._lib.srk_ba_phase_solve(C.c_void_p(self._h))
+        self._raise(rc)
+        return rc == 0
+
+    def phase_backsub(self, hessian_factor):
+        self._raise(self._lib.srk_ba_phase_backsub(C.c_void_p(self._h), C.c_double(hessian_factor)))
+
+    def phase_accept(self):
+        self._raise(self._lib.srk_ba_phase_accept(C.c_void_p(self._h)))
+
+    def buffer(self, which):
+        n = self._lib.srk_ba_buffer_size(C.c_void_p(self._h), int(which))
+        if n < 0:
+            self._raise(int(n))
+        out = np.zeros(max(n, 0))
+        self._raise(self._lib.srk_ba_download(C.c_void_p(self._h), int(which), _p(out), C.c_int64(n)))
+        return out
+
+    def dense_spd_solve(self, A, b):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        n = A.shape[0]
+        x = np.zeros(n)
+        ms = C.c_double(0)
+        rc = self._lib.srk_ba_dense_spd_solve(C.c_void_p(self._h), C.c_int64(n), _p(A), _p(b), _p(x), C.byref(ms))
+        self._raise(rc)
+        return rc == 0, x, ms.value
+
+    # ---- helpers
+    def last_error(self):
+        return self._lib.srk_ba_last_error(C.c_void_p(self._h)).decode()
+
+    def _criteria(self, term_crit):
+        a = m = None
+        self._keep = []
+        if term_crit is not None:
+            if term_crit.AllowedReprojErrRelativeChange() is not None:
+                v = C.c_double(term_crit.AllowedReprojErrRelativeChange())
+                self._keep.append(v)
+                a = C.byref(v)
+            if term_crit.MaxHessianFactor() is not None:
+                v = C.c_double(term_crit.MaxHessianFactor())
+                self._keep.append(v)
+                m = C.byref(v)
+        return a, m
+
+    def _raise(self, rc):
+        if rc >= 0:
+            return
+        msg = self.last_error()
+        if rc == -1:
+            raise ValueError("srk_ba: bad argument: " + msg)
+        if rc == -3:
+            raise RuntimeError("srk_ba: no scene uploaded")
+        if rc == -4:
+            raise MemoryError("srk_ba: out of device memory: " + msg)
+        raise RuntimeError("srk_ba: device error: " + msg)

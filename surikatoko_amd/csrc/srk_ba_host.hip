@@ -1,0 +1,957 @@
+// srk_ba_host.hip -- host side of libsrk_ba.so: the C ABI of include/srk_ba.h, the gauge normalisation, the
+// device-resident Levenberg-Marquardt loop and the buffer management.
+//
+// Mirrors whigg/surikatoko cpp_impl/suriko-engine/src/bundle-adj-kanatani.cpp:
+//   ComputeInplace :617-718, ComputeOnNormalizedWorld :720-893 (LM control), SceneNormalizer :123-333.
+// There is NO CPU fallback: every compute call needs a HIP device and fails loudly (SRK_E_DEVICE) without one.
+#include "../../include/srk_ba.h"
+#include "srk_dev.hpp"
+#include "srk_geom.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct srk_ba {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string last_error;
+
+    // scene
+    bool have_scene = false;
+    SrkDims d{};
+    double f0 = 0;
+    int64_t max_frame_obs = 0;
+    srk_ba_normalizer nrm{};
+    bool normalized_on_upload = false;
+
+    // device buffers
+    DevBuf pts[2], camR[2], camT[2], K, cam[2];
+    DevBuf pts0, camR0, camT0; // copy of the uploaded (normalised) scene for srk_ba_reset_scene
+    DevBuf row_ptr, obs_frame, obs_pt, obs_uv, col_ptr, fobs_pt, fobs_uv;
+    DevBuf W, Vg, Ug, S, rhs, wy, dc, acc, dx, err_partial, err_out, info, scratch;
+    int cur = 0; // index of the current scene buffers; 1-cur = trial
+
+    // multi-GPU exchange
+    srk_allreduce_fn allreduce = nullptr;
+    void* allreduce_ctx = nullptr;
+    int rank = 0, world = 1;
+
+    // timing
+    hipEvent_t ev[16]{};
+    std::vector<hipEvent_t> chol_ev;
+    bool profile_syrk = false;
+    double last_hessian_factor = 0;
+};
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            (h)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+            return SRK_E_DEVICE;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+static int dev_alloc(srk_ba* h, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 8;
+    if (b.p && b.bytes >= bytes) return SRK_OK;
+    if (b.p) {
+        hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        h->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        b.p = nullptr;
+        return e == hipErrorOutOfMemory ? SRK_E_NOMEM : SRK_E_DEVICE;
+    }
+    b.bytes = bytes;
+    return SRK_OK;
+}
+static void dev_free(DevBuf& b)
+{
+    if (b.p) hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+template <typename T> static T* P(const DevBuf& b) { return reinterpret_cast<T*>(b.p); }
+
+extern "C" {
+
+int srk_ba_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+srk_ba* srk_ba_create(int device_id)
+{
+    int n = srk_ba_device_count();
+    if (n <= 0 || device_id < 0 || device_id >= n) {
+        fprintf(stderr, "srk_ba_create: no usable HIP device (count=%d, requested=%d); there is no CPU fallback\n", n,
+                device_id);
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    srk_ba* h = new srk_ba();
+    h->device = device_id;
+    if (hipStreamCreate(&h->stream) != hipSuccess) {
+        delete h;
+        return nullptr;
+    }
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete h;
+            return nullptr;
+        }
+    return h;
+}
+
+void srk_ba_destroy(srk_ba* h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->camR[0], &h->camR[1], &h->camT[0], &h->camT[1], &h->K, &h->cam[0],
+                      &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
+                      &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
+                      &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch };
+    for (DevBuf* b : all) dev_free(*b);
+    for (auto& e : h->ev)
+        if (e) hipEventDestroy(e);
+    for (auto& e : h->chol_ev) hipEventDestroy(e);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* srk_ba_last_error(const srk_ba* h) { return h ? h->last_error.c_str() : "null handle"; }
+
+const char* srk_ba_status_string(int status)
+{
+    switch (status) {
+    case SRK_STATUS_ABS_ERR_THRESHOLD: return "abs err threshold";
+    case SRK_STATUS_SMALL_ERR_CHANGE: return "small relative err change";
+    case SRK_STATUS_HESSIAN_OVERFLOW: return "hessian overflow";
+    case SRK_STATUS_ERR_CONVERGED: return "err converged to limit value";
+    case SRK_STATUS_MAX_ITERATIONS: return "max iterations";
+    case SRK_STATUS_DEVICE_ERROR: return "device error";
+    default: return "";
+    }
+}
+
+int srk_ba_set_stream(srk_ba* h, void* hip_stream)
+{
+    if (!h) return SRK_E_ARGS;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+    return SRK_OK;
+}
+
+int srk_ba_set_allreduce(srk_ba* h, srk_allreduce_fn fn, void* ctx, int rank, int world_size)
+{
+    if (!h || world_size < 1 || rank < 0 || rank >= world_size) return SRK_E_ARGS;
+    h->allreduce = fn;
+    h->allreduce_ctx = ctx;
+    h->rank = rank;
+    h->world = world_size;
+    return SRK_OK;
+}
+
+// ------------------------------------------------------------------ host normalisation (bundle-adj-kanatani.cpp:123-333)
+
+int srk_ba_check_world_is_normalized(int32_t M, const double* cam_R, const double* cam_T, double t1y, int32_t comp)
+{
+    if (M < 2 || !cam_R || !cam_T || comp < 0 || comp > 2) return 0; // :291-292
+    const double atol = 1e-3;                                           // :297
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            if (!srk::is_close(r == c ? 1.0 : 0.0, cam_R[3 * r + c], atol, atol)) return 0; // :299 IsIdentity
+    if (srk::norm3(cam_T) >= atol) return 0;                                                  // :308-309
+    double Ri[9], Ti[3];
+    srk::se3_inv(cam_R + 9, cam_T + 3, Ri, Ti);                                               // :320
+    return srk::is_close(t1y, std::fabs(Ti[comp]), atol) ? 1 : 0;                             // :323
+}
+
+int srk_ba_normalize_scene(int64_t N, double* pts, int32_t M, double* cam_R, double* cam_T, double t1y, int32_t comp,
+                           srk_ba_normalizer* out)
+{
+    if (M < 2 || comp < 0 || comp > 2 || !out || !cam_R || !cam_T || (N > 0 && !pts)) return 0;
+    // cam0_from1 = SE3AFromB(cam0, cam1)  (:208, obs-geom.cpp:141-150)
+    double R1i[9], T1i[3], v[3], T01[3];
+    srk::se3_inv(cam_R + 9, cam_T + 3, R1i, T1i);
+    srk::mat3_vec(cam_R, T1i, v);
+    for (int i = 0; i < 3; ++i) T01[i] = v[i] + cam_T[i];
+    double shift = T01[comp];
+    if (srk::is_close(0.0, shift, 1e-5)) return 0; // :215-217 (the lone third argument is rtol)
+    double s = t1y / std::fabs(shift);             // :219
+    std::memcpy(out->R0, cam_R, sizeof out->R0);
+    std::memcpy(out->T0, cam_T, sizeof out->T0);
+    out->world_scale = s;
+    double R0t[9];
+    srk::mat3_tr(out->R0, R0t);
+    for (int32_t j = 0; j < M; ++j) { // NormalizeRT :143-162
+        double RR[9], u[3];
+        srk::mat3_mul(cam_R + 9 * (int64_t)j, R0t, RR);
+        srk::mat3_vec(RR, out->T0, u);
+        for (int i = 0; i < 3; ++i) cam_T[3 * (int64_t)j + i] = (cam_T[3 * (int64_t)j + i] - u[i]) * s;
+        std::memcpy(cam_R + 9 * (int64_t)j, RR, sizeof RR);
+    }
+    for (int64_t i = 0; i < N; ++i) { // :179-199
+        double y[3];
+        srk::se3_apply(out->R0, out->T0, pts + 3 * i, y);
+        pts[3 * i] = y[0] * s;
+        pts[3 * i + 1] = y[1] * s;
+        pts[3 * i + 2] = y[2] * s;
+    }
+    return 1;
+}
+
+void srk_ba_revert_normalization(int64_t N, double* pts, int32_t M, double* cam_R, double* cam_T,
+                                 const srk_ba_normalizer* nrm)
+{
+    double s = nrm->world_scale;
+    double R0t[9];
+    srk::mat3_tr(nrm->R0, R0t);
+    for (int64_t i = 0; i < N; ++i) { // :187-191
+        double is = 1 / s;
+        double t[3] = { pts[3 * i] * is - nrm->T0[0], pts[3 * i + 1] * is - nrm->T0[1], pts[3 * i + 2] * is - nrm->T0[2] };
+        srk::mat3_vec(R0t, t, pts + 3 * i);
+    }
+    for (int32_t j = 0; j < M; ++j) { // RevertRT :164-177
+        double RR[9], u[3];
+        double* R = cam_R + 9 * (int64_t)j;
+        double* T = cam_T + 3 * (int64_t)j;
+        srk::mat3_mul(R, nrm->R0, RR);
+        srk::mat3_vec(R, nrm->T0, u);
+        for (int i = 0; i < 3; ++i) T[i] = T[i] / s + u[i];
+        std::memcpy(R, RR, sizeof RR);
+    }
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ scene upload
+
+static int validate_scene(srk_ba* h, double f0, int64_t N, const double* pts, int32_t M, const double* cam_R,
+                          const double* cam_T, const double* K, const int64_t* row_ptr, const int32_t* obs_frame,
+                          const double* obs_uv)
+{
+    if (!h) return SRK_E_ARGS;
+    // CHECK(!IsClose(0, f0)) (:420)
+    if (srk::is_close(0.0, f0)) { h->last_error = "f0 must not be ~0"; return SRK_E_ARGS; }
+    if (M < 2) { h->last_error = "need at least two frames"; return SRK_E_ARGS; }
+    if (N < 0 || !cam_R || !cam_T || !K || !row_ptr) { h->last_error = "null scene array"; return SRK_E_ARGS; }
+    if (N > 0 && !pts) { h->last_error = "null points"; return SRK_E_ARGS; }
+    if (N > 2147483000LL) { h->last_error = "too many points for int32 indices"; return SRK_E_ARGS; }
+    if (row_ptr[0] != 0) { h->last_error = "obs_row_ptr[0] != 0"; return SRK_E_ARGS; }
+    int64_t O = row_ptr[N];
+    if (O > 0 && (!obs_frame || !obs_uv)) { h->last_error = "null observation arrays"; return SRK_E_ARGS; }
+    for (int64_t i = 0; i < N; ++i) {
+        if (row_ptr[i + 1] < row_ptr[i]) { h->last_error = "obs_row_ptr not monotone"; return SRK_E_ARGS; }
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o) {
+            int32_t j = obs_frame[o];
+            if (j < 0 || j >= M) { h->last_error = "obs_frame out of range"; return SRK_E_ARGS; }
+            if (o > row_ptr[i] && obs_frame[o - 1] >= j) {
+                h->last_error = "obs_frame must be strictly ascending inside a point";
+                return SRK_E_ARGS;
+            }
+        }
+    }
+    return SRK_OK;
+}
+
+static int compute_cam_packs(srk_ba* h, int which)
+{
+    srk_launch_cam_pack(h->stream, h->d.M, P<double>(h->camR[which]), P<double>(h->camT[which]), P<double>(h->K),
+                        h->f0, P<double>(h->cam[which]));
+    HIPCHK(h, hipGetLastError());
+    return SRK_OK;
+}
+
+extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
+                                   const double* cam_R_in, const double* cam_T_in, const double* K_in, int shared_k,
+                                   const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                                   int already_normalized)
+{
+    int rc = validate_scene(h, f0, N, pts_in, M, cam_R_in, cam_T_in, K_in, row_ptr, obs_frame, obs_uv);
+    if (rc != SRK_OK) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->have_scene = false;
+    int64_t O = row_ptr[N];
+    std::vector<double> pts(pts_in, pts_in + 3 * N), camR(cam_R_in, cam_R_in + 9 * (int64_t)M),
+        camT(cam_T_in, cam_T_in + 3 * (int64_t)M);
+    h->normalized_on_upload = false;
+    if (!already_normalized) {
+        // unity_t1_comp_ind_ = 1, unity_t1_comp_value_ = 1.0 (bundle-adj-kanatani.h:131-132); :680-682
+        if (!srk_ba_normalize_scene(N, pts.data(), M, camR.data(), camT.data(), 1.0, 1, &h->nrm)) {
+            h->last_error = "scene cannot be normalised (cam0->cam1 translation component ~ 0)";
+            return 1; // reference: ComputeInplace returns false, status string stays empty
+        }
+        h->normalized_on_upload = true;
+    } else {
+        std::memset(&h->nrm, 0, sizeof h->nrm);
+        h->nrm.R0[0] = h->nrm.R0[4] = h->nrm.R0[8] = 1;
+        h->nrm.world_scale = 1;
+    }
+    std::vector<double> Kexp(9 * (int64_t)M);
+    for (int32_t j = 0; j < M; ++j) std::memcpy(&Kexp[9 * (int64_t)j], shared_k ? K_in : K_in + 9 * (int64_t)j, 72);
+
+    SrkDims d{};
+    d.N = N;
+    d.M = M;
+    d.O = O;
+    d.Os = ((O + 63) / 64) * 64;
+    if (d.Os == 0) d.Os = 64;
+    d.Ns = ((N + 63) / 64) * 64;
+    if (d.Ns == 0) d.Ns = 64;
+    d.ld = ((10 * (int64_t)M + SRK_CHOL_NB - 1) / SRK_CHOL_NB) * SRK_CHOL_NB;
+    d.comp = 1;
+    h->d = d;
+    h->f0 = f0;
+
+    // observation side tables: obs -> point, and the frame-major copy (ordered by frame, then pnt_ind)
+    std::vector<int32_t> obs_pt((size_t)O);
+    std::vector<int64_t> col_ptr((size_t)M + 1, 0);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o) {
+            obs_pt[(size_t)o] = (int32_t)i;
+            col_ptr[(size_t)obs_frame[o] + 1]++;
+        }
+    h->max_frame_obs = 0;
+    for (int32_t j = 0; j < M; ++j) {
+        if (col_ptr[(size_t)j + 1] > h->max_frame_obs) h->max_frame_obs = col_ptr[(size_t)j + 1];
+        col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
+    }
+    std::vector<int32_t> fobs_pt((size_t)O);
+    std::vector<double> fobs_uv((size_t)(2 * O));
+    {
+        std::vector<int64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+        for (int64_t o = 0; o < O; ++o) {
+            int64_t k = fill[(size_t)obs_frame[o]]++;
+            fobs_pt[(size_t)k] = obs_pt[(size_t)o];
+            fobs_uv[(size_t)(2 * k)] = obs_uv[2 * o];
+            fobs_uv[(size_t)(2 * k + 1)] = obs_uv[2 * o + 1];
+        }
+    }
+
+#define ALLOC(buf, bytes)                              \
+    do {                                               \
+        int _r = dev_alloc(h, (buf), (size_t)(bytes)); \
+        if (_r != SRK_OK) return _r;                   \
+    } while (0)
+    for (int w = 0; w < 2; ++w) {
+        ALLOC(h->pts[w], 24 * N);
+        ALLOC(h->camR[w], 72 * (int64_t)M);
+        ALLOC(h->camT[w], 24 * (int64_t)M);
+        ALLOC(h->cam[w], 8 * SRK_CAM_PACK * (int64_t)M);
+    }
+    ALLOC(h->pts0, 24 * N);
+    ALLOC(h->camR0, 72 * (int64_t)M);
+    ALLOC(h->camT0, 24 * (int64_t)M);
+    ALLOC(h->K, 72 * (int64_t)M);
+    ALLOC(h->row_ptr, 8 * (N + 1));
+    ALLOC(h->obs_frame, 4 * O);
+    ALLOC(h->obs_pt, 4 * O);
+    ALLOC(h->obs_uv, 16 * O);
+    ALLOC(h->col_ptr, 8 * ((int64_t)M + 1));
+    ALLOC(h->fobs_pt, 4 * O);
+    ALLOC(h->fobs_uv, 16 * O);
+    ALLOC(h->W, 8 * 30 * d.Os);
+    ALLOC(h->Vg, 8 * 9 * d.Ns);
+    ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
+    ALLOC(h->S, 8 * d.ld * d.ld);
+    ALLOC(h->rhs, 8 * d.ld);
+    ALLOC(h->wy, 8 * 2 * d.ld);
+    ALLOC(h->dc, 8 * d.ld);
+    ALLOC(h->acc, 8 * 3 * d.Ns + 64);
+    ALLOC(h->dx, 24 * N);
+    ALLOC(h->err_partial, 8 * 1024);
+    ALLOC(h->err_out, 64);
+    ALLOC(h->info, 64);
+#undef ALLOC
+    hipStream_t s = h->stream;
+#define H2D(buf, src, bytes)                                                                               \
+    do {                                                                                                   \
+        if ((bytes) > 0) HIPCHK(h, hipMemcpyAsync((buf).p, (src), (size_t)(bytes), hipMemcpyHostToDevice, s)); \
+    } while (0)
+    H2D(h->pts[0], pts.data(), 24 * N);
+    H2D(h->camR[0], camR.data(), 72 * (int64_t)M);
+    H2D(h->camT[0], camT.data(), 24 * (int64_t)M);
+    H2D(h->pts0, pts.data(), 24 * N);
+    H2D(h->camR0, camR.data(), 72 * (int64_t)M);
+    H2D(h->camT0, camT.data(), 24 * (int64_t)M);
+    H2D(h->K, Kexp.data(), 72 * (int64_t)M);
+    H2D(h->row_ptr, row_ptr, 8 * (N + 1));
+    H2D(h->obs_frame, obs_frame, 4 * O);
+    H2D(h->obs_pt, obs_pt.data(), 4 * O);
+    H2D(h->obs_uv, obs_uv, 16 * O);
+    H2D(h->col_ptr, col_ptr.data(), 8 * ((int64_t)M + 1));
+    H2D(h->fobs_pt, fobs_pt.data(), 4 * O);
+    H2D(h->fobs_uv, fobs_uv.data(), 16 * O);
+#undef H2D
+    HIPCHK(h, hipMemsetAsync(h->dc.p, 0, 8 * d.ld, s));
+    HIPCHK(h, hipMemsetAsync(h->dx.p, 0, 24 * N > 0 ? 24 * N : 8, s));
+    h->cur = 0;
+    rc = compute_cam_packs(h, 0);
+    if (rc != SRK_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(s)); // host staging vectors go out of scope
+    h->have_scene = true;
+    return SRK_OK;
+}
+
+extern "C" int srk_ba_reset_scene(srk_ba* h)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    h->cur = 0;
+    if (h->d.N > 0) HIPCHK(h, hipMemcpyAsync(h->pts[0].p, h->pts0.p, 24 * h->d.N, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->camR[0].p, h->camR0.p, 72 * (int64_t)h->d.M, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->camT[0].p, h->camT0.p, 24 * (int64_t)h->d.M, hipMemcpyDeviceToDevice, s));
+    return compute_cam_packs(h, 0);
+}
+
+extern "C" int srk_ba_download_scene(srk_ba* h, double* pts, double* cam_R, double* cam_T, int revert)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int c = h->cur;
+    if (h->d.N > 0) HIPCHK(h, hipMemcpyAsync(pts, h->pts[c].p, 24 * h->d.N, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(cam_R, h->camR[c].p, 72 * (int64_t)h->d.M, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(cam_T, h->camT[c].p, 24 * (int64_t)h->d.M, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (revert && h->normalized_on_upload) srk_ba_revert_normalization(h->d.N, pts, h->d.M, cam_R, cam_T, &h->nrm); // :706
+    return SRK_OK;
+}
+
+// ------------------------------------------------------------------ phases
+
+static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
+{
+    if (h->world <= 1 || !h->allreduce) return SRK_OK;
+    int rc = h->allreduce(h->allreduce_ctx, dev_ptr, count);
+    if (rc != 0) {
+        h->last_error = "allreduce hook failed";
+        return SRK_E_DEVICE;
+    }
+    return SRK_OK;
+}
+
+static int phase_error(srk_ba* h, int which, double* err_host)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    int32_t np = srk_error_partials(d);
+    srk_launch_error(s, d, P<double>(h->pts[which]), P<double>(h->cam[which]), P<int32_t>(h->obs_frame),
+                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->err_partial), np, P<double>(h->err_out));
+    HIPCHK(h, hipGetLastError());
+    int rc = exchange(h, P<double>(h->err_out), 1);
+    if (rc != SRK_OK) return rc;
+    if (err_host) {
+        HIPCHK(h, hipMemcpyAsync(err_host, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    return SRK_OK;
+}
+
+static int phase_derivatives(srk_ba* h)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    int c = h->cur;
+    HIPCHK(h, hipMemsetAsync(h->Vg.p, 0, 8 * 9 * d.Ns, s));
+    HIPCHK(h, hipMemsetAsync(h->Ug.p, 0, 8 * SRK_UG * (int64_t)d.M, s));
+    HIPCHK(h, hipEventRecord(h->ev[12], s));
+    srk_launch_jac_points(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
+                          P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg));
+    HIPCHK(h, hipEventRecord(h->ev[13], s));
+    srk_launch_jac_frames(s, d, h->max_frame_obs, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->col_ptr),
+                          P<int32_t>(h->fobs_pt), P<double>(h->fobs_uv), P<double>(h->Ug));
+    HIPCHK(h, hipGetLastError());
+    return exchange(h, P<double>(h->Ug), SRK_UG * (int64_t)d.M); // frame blocks + frame gradients over all shards
+}
+
+static int phase_schur(srk_ba* h, double c)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemsetAsync(h->S.p, 0, 8 * d.ld * d.ld, s));
+    HIPCHK(h, hipMemsetAsync(h->rhs.p, 0, 8 * d.ld, s));
+    srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
+                     P<double>(h->S), P<double>(h->rhs));
+    HIPCHK(h, hipGetLastError());
+    // landmark shards: sum the partial Schur sums and right-hand sides, then add the (global) frame blocks
+    int rc = exchange(h, P<double>(h->S), d.ld * d.ld);
+    if (rc != SRK_OK) return rc;
+    rc = exchange(h, P<double>(h->rhs), d.ld);
+    if (rc != SRK_OK) return rc;
+    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->S), P<double>(h->rhs));
+    HIPCHK(h, hipGetLastError());
+    h->last_hessian_factor = c;
+    return SRK_OK;
+}
+
+static int phase_solve(srk_ba* h, bool profile)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemsetAsync(h->info.p, 0, 4, s));
+    hipEvent_t* evs = nullptr;
+    if (profile) {
+        size_t need = (size_t)(2 * (d.ld / SRK_CHOL_NB));
+        while (h->chol_ev.size() < need) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e));
+            h->chol_ev.push_back(e);
+        }
+        evs = h->chol_ev.data();
+    }
+    double* wy = P<double>(h->wy);
+    srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info), evs);
+    HIPCHK(h, hipGetLastError());
+    return SRK_OK;
+}
+
+static int read_info(srk_ba* h, int* info_host)
+{
+    HIPCHK(h, hipMemcpyAsync(info_host, h->info.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SRK_OK;
+}
+
+static int phase_backsub_apply(srk_ba* h, double c)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    int cur = h->cur, tr = 1 - h->cur;
+    HIPCHK(h, hipMemsetAsync(h->acc.p, 0, 8 * 3 * d.Ns + 64, s));
+    srk_launch_backsub(s, d, c, P<int32_t>(h->obs_frame), P<int32_t>(h->obs_pt), P<double>(h->W), P<double>(h->Vg),
+                       P<double>(h->dc), P<double>(h->acc), P<double>(h->pts[cur]), P<double>(h->pts[tr]),
+                       P<double>(h->dx));
+    HIPCHK(h, hipGetLastError());
+    return SRK_OK;
+}
+
+static int phase_cam_apply(srk_ba* h)
+{
+    int cur = h->cur, tr = 1 - h->cur;
+    srk_launch_cam_apply(h->stream, h->d.M, P<double>(h->camR[cur]), P<double>(h->camT[cur]), P<double>(h->dc),
+                         P<double>(h->camR[tr]), P<double>(h->camT[tr]));
+    HIPCHK(h, hipGetLastError());
+    return compute_cam_packs(h, tr);
+}
+
+extern "C" {
+
+int srk_ba_phase_error(srk_ba* h, double* err, int64_t* seen)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (seen) *seen = h->d.O;
+    return phase_error(h, h->cur, err);
+}
+int srk_ba_phase_derivatives(srk_ba* h)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = phase_derivatives(h);
+    if (rc != SRK_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SRK_OK;
+}
+int srk_ba_phase_schur(srk_ba* h, double c)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = phase_schur(h, c);
+    if (rc != SRK_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SRK_OK;
+}
+int srk_ba_phase_solve(srk_ba* h)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = phase_solve(h, false);
+    if (rc != SRK_OK) return rc;
+    int info = 0;
+    rc = read_info(h, &info);
+    if (rc != SRK_OK) return rc;
+    return info ? 1 : 0;
+}
+int srk_ba_phase_backsub(srk_ba* h, double c)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = phase_backsub_apply(h, c);
+    if (rc != SRK_OK) return rc;
+    rc = phase_cam_apply(h);
+    if (rc != SRK_OK) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SRK_OK;
+}
+int srk_ba_phase_accept(srk_ba* h)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    h->cur = 1 - h->cur;
+    return SRK_OK;
+}
+
+// ------------------------------------------------------------------ the LM loop (bundle-adj-kanatani.cpp:720-893)
+
+int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* max_hessian_factor,
+                    int64_t max_iterations, srk_ba_report* rep)
+{
+    srk_ba_report local;
+    if (!rep) rep = &local;
+    std::memset(rep, 0, sizeof *rep);
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const SrkDims& d = h->d;
+    auto t_begin = std::chrono::steady_clock::now();
+    rep->world_scale = h->nrm.world_scale;
+
+    auto fail_device = [&](int rc) {
+        rep->status = SRK_STATUS_DEVICE_ERROR;
+        rep->optimized = 0;
+        return rc;
+    };
+    auto ev_ms = [&](int a, int b) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->ev[a], h->ev[b]);
+        return (double)ms;
+    };
+
+    double hessian_factor = (double)0.0001f; // :723 (float literal)
+    // seen_points_count over all shards (:483, :726)
+    double seen_d = (double)d.O;
+    if (h->world > 1 && h->allreduce) {
+        HIPCHK(h, hipMemcpyAsync(h->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
+        int rc = exchange(h, P<double>(h->err_out), 1);
+        if (rc != SRK_OK) return fail_device(rc);
+        HIPCHK(h, hipMemcpyAsync(&seen_d, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    rep->seen = (int64_t)seen_d;
+
+    double err_initial = 0;
+    HIPCHK(h, hipEventRecord(h->ev[0], s));
+    int rc = phase_error(h, h->cur, nullptr);
+    if (rc != SRK_OK) return fail_device(rc);
+    HIPCHK(h, hipEventRecord(h->ev[1], s));
+    HIPCHK(h, hipMemcpyAsync(&err_initial, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    rep->ms_error += ev_ms(0, 1);
+    rep->err_initial = rep->err_final = err_initial;
+
+    bool result_true = false;
+    bool done = false;
+    if (allowed_err_change && err_initial < *allowed_err_change) { // :749-753
+        rep->status = SRK_STATUS_ABS_ERR_THRESHOLD;
+        result_true = true;
+        done = true;
+    }
+    double err_value = err_initial;
+    while (!done) {
+        if (max_iterations > 0 && rep->iterations >= max_iterations) {
+            rep->status = SRK_STATUS_MAX_ITERATIONS;
+            result_true = false;
+            break;
+        }
+        // ComputeCloseFormReprErrorDerivatives (:759)
+        HIPCHK(h, hipEventRecord(h->ev[0], s));
+        rc = phase_derivatives(h);
+        if (rc != SRK_OK) return fail_device(rc);
+        HIPCHK(h, hipEventRecord(h->ev[1], s));
+        rep->jacobian_launches += 2;
+        bool jac_timed = false;
+
+        // try_decrease_targ_fun (:764-852): the backup is the untouched `cur` buffer set, the trial lives in 1-cur
+        bool have_prev = false;
+        double err_new_prev = 0, err_new = std::nan("");
+        int decrease = 0; // 1 success, 2 hessian overflow, 3 converged
+        while (!decrease) {
+            rep->attempts += 1;
+            HIPCHK(h, hipEventRecord(h->ev[2], s));
+            rc = phase_schur(h, hessian_factor);
+            if (rc != SRK_OK) return fail_device(rc);
+            HIPCHK(h, hipEventRecord(h->ev[3], s));
+            rc = phase_solve(h, h->profile_syrk);
+            if (rc != SRK_OK) return fail_device(rc);
+            HIPCHK(h, hipEventRecord(h->ev[4], s));
+            rc = phase_backsub_apply(h, hessian_factor);
+            if (rc != SRK_OK) return fail_device(rc);
+            HIPCHK(h, hipEventRecord(h->ev[5], s));
+            rc = phase_cam_apply(h);
+            if (rc != SRK_OK) return fail_device(rc);
+            HIPCHK(h, hipEventRecord(h->ev[6], s));
+            rc = phase_error(h, 1 - h->cur, nullptr);
+            if (rc != SRK_OK) return fail_device(rc);
+            HIPCHK(h, hipEventRecord(h->ev[7], s));
+            struct { double err; int info; } back;
+            HIPCHK(h, hipMemcpyAsync(&back.err, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(&back.info, h->info.p, 4, hipMemcpyDeviceToHost, s));
+            // the point-update finite flag lives behind acc (set by k_point_update)
+            int info2 = 0;
+            HIPCHK(h, hipMemcpyAsync(&info2, reinterpret_cast<char*>(h->acc.p) + 8 * 3 * d.Ns, 4,
+                                     hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (!jac_timed) {
+                rep->ms_jacobian += ev_ms(0, 1);
+                rep->ms_jacobian_kernel += ev_ms(12, 13);
+                jac_timed = true;
+            }
+            rep->ms_schur += ev_ms(2, 3);
+            rep->ms_solve += ev_ms(3, 4);
+            rep->ms_backsub += ev_ms(4, 5);
+            rep->ms_apply += ev_ms(5, 6);
+            rep->ms_error += ev_ms(6, 7);
+            rep->schur_launches += 2;
+            if (h->profile_syrk) {
+                int64_t nblk = d.ld / SRK_CHOL_NB;
+                for (int64_t kb = 0; kb + 1 < nblk; ++kb) {
+                    float ms = 0;
+                    if (hipEventElapsedTime(&ms, h->chol_ev[(size_t)(2 * kb)], h->chol_ev[(size_t)(2 * kb + 1)]) == hipSuccess)
+                        rep->ms_solve_syrk += ms;
+                }
+            }
+            if (back.info != 0 || info2 != 0) { decrease = 2; break; } // solve failed (:807-808, :1912-1913, :1953-1954)
+            err_new = back.err;
+            if (err_new - err_value < 0) { decrease = 1; break; } // :816-819
+            // restore = drop the trial buffers (:823-826)
+            if (have_prev && allowed_err_change) { // :828-838
+                double change = err_new - err_new_prev;
+                if (std::fabs(change) < *allowed_err_change) { decrease = 3; break; }
+            }
+            hessian_factor *= 10; // :841
+            if (max_hessian_factor && hessian_factor > *max_hessian_factor) { decrease = 2; break; } // :843-847
+            err_new_prev = err_new;
+            have_prev = true;
+        }
+        if (decrease != 1) { // :857-873
+            rep->status = decrease == 2 ? SRK_STATUS_HESSIAN_OVERFLOW : SRK_STATUS_ERR_CONVERGED;
+            result_true = false;
+            break;
+        }
+        h->cur = 1 - h->cur; // accept: the trial scene becomes current
+        rep->iterations += 1;
+        double change = err_new - err_value;
+        rep->err_final = err_new;
+        if (allowed_err_change && std::fabs(change) < *allowed_err_change) { // :880-884
+            rep->status = SRK_STATUS_SMALL_ERR_CHANGE;
+            result_true = true;
+            break;
+        }
+        err_value = err_new;
+        hessian_factor /= 10; // :889
+    }
+    rep->hessian_factor = hessian_factor;
+    rep->optimized = result_true ? 1 : 0;
+    rep->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return result_true ? 0 : 1;
+}
+
+int srk_ba_compute_inplace(srk_ba* h, double f0, int64_t N, double* pts, int32_t M, double* cam_R, double* cam_T,
+                           const double* K, int shared_k, const int64_t* row_ptr, const int32_t* obs_frame,
+                           const double* obs_uv, const double* allowed_err_change, const double* max_hessian_factor,
+                           int64_t max_iterations, srk_ba_report* rep)
+{
+    srk_ba_report local;
+    if (!rep) rep = &local;
+    std::memset(rep, 0, sizeof *rep);
+    if (!h) return SRK_E_ARGS;
+    int rc = srk_ba_upload_scene(h, f0, N, pts, M, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv, 0);
+    if (rc == 1) { // normalisation failed: reference returns false with an empty status string (:681-682)
+        rep->status = SRK_STATUS_NONE;
+        return 1;
+    }
+    if (rc != SRK_OK) return rc;
+    int result = srk_ba_optimize(h, allowed_err_change, max_hessian_factor, max_iterations, rep);
+    if (result < 0) return result;
+    rc = srk_ba_download_scene(h, pts, cam_R, cam_T, 1);
+    if (rc != SRK_OK) return rc;
+    return result;
+}
+
+double srk_ba_reproj_error(srk_ba* h, double f0, int64_t N, const double* pts, int32_t M, const double* cam_R,
+                           const double* cam_T, const double* K, int shared_k, const int64_t* row_ptr,
+                           const int32_t* obs_frame, const double* obs_uv, int64_t* seen)
+{
+    if (!h) return std::nan("");
+    int rc = srk_ba_upload_scene(h, f0, N, pts, M, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv, 1);
+    if (rc != SRK_OK) return std::nan("");
+    double e = std::nan("");
+    if (srk_ba_phase_error(h, &e, seen) != SRK_OK) return std::nan("");
+    return e;
+}
+
+// ------------------------------------------------------------------ downloads for the parity tests
+
+int64_t srk_ba_buffer_size(srk_ba* h, int which)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    const SrkDims& d = h->d;
+    switch (which) {
+    case SRK_BUF_GRAD: return 3 * d.N + 10 * (int64_t)d.M;
+    case SRK_BUF_POINT_BLOCKS: return 9 * d.N;
+    case SRK_BUF_FRAME_BLOCKS: return 100 * (int64_t)d.M;
+    case SRK_BUF_POINT_FRAME: return 30 * d.O;
+    case SRK_BUF_RCS: return 100 * (int64_t)d.M * d.M;
+    case SRK_BUF_RCS_RHS: return 10 * (int64_t)d.M;
+    case SRK_BUF_CORRECTIONS: return 3 * d.N + 10 * (int64_t)d.M;
+    case SRK_BUF_POINTS: return 3 * d.N;
+    case SRK_BUF_CAM_R: return 9 * (int64_t)d.M;
+    case SRK_BUF_CAM_T: return 3 * (int64_t)d.M;
+    default: return SRK_E_ARGS;
+    }
+}
+
+int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
+{
+    if (!h || !h->have_scene || !dst) return SRK_E_STATE;
+    if (count != srk_ba_buffer_size(h, which)) { h->last_error = "download: wrong count"; return SRK_E_ARGS; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+    auto d2h = [&](void* dstp, const void* src, size_t bytes) -> int {
+        if (bytes == 0) return SRK_OK;
+        HIPCHK(h, hipMemcpy(dstp, src, bytes, hipMemcpyDeviceToHost));
+        return SRK_OK;
+    };
+    int rc = SRK_OK;
+    switch (which) {
+    case SRK_BUF_GRAD:
+    case SRK_BUF_POINT_BLOCKS: {
+        std::vector<double> vg((size_t)(9 * d.Ns));
+        if ((rc = d2h(vg.data(), h->Vg.p, vg.size() * 8)) != SRK_OK) return rc;
+        if (which == SRK_BUF_POINT_BLOCKS) {
+            static const int map[9] = { 0, 1, 2, 1, 3, 4, 2, 4, 5 };
+            for (int64_t i = 0; i < d.N; ++i)
+                for (int e = 0; e < 9; ++e) dst[9 * i + e] = vg[(size_t)(map[e] * d.Ns + i)];
+            return SRK_OK;
+        }
+        for (int64_t i = 0; i < d.N; ++i)
+            for (int e = 0; e < 3; ++e) dst[3 * i + e] = vg[(size_t)((6 + e) * d.Ns + i)];
+        std::vector<double> ug((size_t)(SRK_UG * (int64_t)d.M));
+        if ((rc = d2h(ug.data(), h->Ug.p, ug.size() * 8)) != SRK_OK) return rc;
+        for (int32_t j = 0; j < d.M; ++j)
+            for (int e = 0; e < 10; ++e) dst[3 * d.N + 10 * (int64_t)j + e] = ug[(size_t)(SRK_UG * (int64_t)j + 55 + e)];
+        return SRK_OK;
+    }
+    case SRK_BUF_FRAME_BLOCKS: {
+        std::vector<double> ug((size_t)(SRK_UG * (int64_t)d.M));
+        if ((rc = d2h(ug.data(), h->Ug.p, ug.size() * 8)) != SRK_OK) return rc;
+        for (int32_t j = 0; j < d.M; ++j)
+            for (int v1 = 0; v1 < 10; ++v1)
+                for (int v2 = 0; v2 < 10; ++v2) {
+                    int a = v1 < v2 ? v1 : v2, b = v1 < v2 ? v2 : v1;
+                    dst[100 * (int64_t)j + 10 * v1 + v2] = ug[(size_t)(SRK_UG * (int64_t)j + a * 10 - a * (a - 1) / 2 + (b - a))];
+                }
+        return SRK_OK;
+    }
+    case SRK_BUF_POINT_FRAME: {
+        std::vector<double> w((size_t)(30 * d.Os));
+        if ((rc = d2h(w.data(), h->W.p, w.size() * 8)) != SRK_OK) return rc;
+        for (int64_t o = 0; o < d.O; ++o)
+            for (int k = 0; k < 30; ++k) dst[30 * o + k] = w[(size_t)(k * d.Os + o)];
+        return SRK_OK;
+    }
+    case SRK_BUF_RCS: {
+        int64_t n = 10 * (int64_t)d.M;
+        std::vector<double> row((size_t)d.ld);
+        for (int64_t r = 0; r < n; ++r) {
+            if ((rc = d2h(row.data(), P<double>(h->S) + r * d.ld, (size_t)(8 * n))) != SRK_OK) return rc;
+            for (int64_t c = 0; c <= r; ++c) {
+                dst[r * n + c] = row[(size_t)c];
+                dst[c * n + r] = row[(size_t)c]; // lower triangle is authoritative
+            }
+        }
+        return SRK_OK;
+    }
+    case SRK_BUF_RCS_RHS: return d2h(dst, h->rhs.p, (size_t)(80 * (int64_t)d.M));
+    case SRK_BUF_CORRECTIONS: {
+        if ((rc = d2h(dst, h->dx.p, (size_t)(24 * d.N))) != SRK_OK) return rc;
+        return d2h(dst + 3 * d.N, h->dc.p, (size_t)(80 * (int64_t)d.M));
+    }
+    case SRK_BUF_POINTS: return d2h(dst, h->pts[h->cur].p, (size_t)(24 * d.N));
+    case SRK_BUF_CAM_R: return d2h(dst, h->camR[h->cur].p, (size_t)(72 * (int64_t)d.M));
+    case SRK_BUF_CAM_T: return d2h(dst, h->camT[h->cur].p, (size_t)(24 * (int64_t)d.M));
+    default: return SRK_E_ARGS;
+    }
+}
+
+// ------------------------------------------------------------------ dense SPD solve on its own
+
+int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* b, double* x, double* ms_factor)
+{
+    if (!h || n <= 0 || !A || !b || !x) return SRK_E_ARGS;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int64_t ld = ((n + SRK_CHOL_NB - 1) / SRK_CHOL_NB) * SRK_CHOL_NB;
+    DevBuf dA, dw, dy, dx, dinfo;
+    int rc;
+    if ((rc = dev_alloc(h, dA, (size_t)(8 * ld * ld))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, dw, (size_t)(8 * ld))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, dy, (size_t)(8 * ld))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, dx, (size_t)(8 * ld))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, dinfo, 64)) != SRK_OK) return rc;
+    std::vector<double> Ap((size_t)(ld * ld), 0.0), bp((size_t)ld, 0.0);
+    for (int64_t r = 0; r < ld; ++r) {
+        if (r < n) std::memcpy(&Ap[(size_t)(r * ld)], A + r * n, (size_t)(8 * n));
+        else Ap[(size_t)(r * ld + r)] = 1.0;
+    }
+    std::memcpy(bp.data(), b, (size_t)(8 * n));
+    HIPCHK(h, hipMemcpyAsync(dA.p, Ap.data(), Ap.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dw.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(dinfo.p, 0, 4, s));
+    HIPCHK(h, hipEventRecord(h->ev[14], s));
+    srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr);
+    HIPCHK(h, hipEventRecord(h->ev[15], s));
+    HIPCHK(h, hipGetLastError());
+    int info = 0;
+    HIPCHK(h, hipMemcpyAsync(bp.data(), dx.p, bp.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(&info, dinfo.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (ms_factor) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->ev[14], h->ev[15]);
+        *ms_factor = ms;
+    }
+    std::memcpy(x, bp.data(), (size_t)(8 * n));
+    dev_free(dA); dev_free(dw); dev_free(dy); dev_free(dx); dev_free(dinfo);
+    return info ? 1 : 0;
+}
+
+// knob for bench.py: event pairs around every MFMA trailing-update launch (report.ms_solve_syrk)
+int srk_ba_set_profile(srk_ba* h, int profile_syrk)
+{
+    if (!h) return SRK_E_ARGS;
+    h->profile_syrk = profile_syrk != 0;
+    return SRK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,647 @@
+// srk_ba_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the Kanatani BA hot path.
+//
+// Reference being accelerated (whigg/surikatoko, cpp_impl/suriko-engine/src/bundle-adj-kanatani.cpp):
+//   reprojection error                :410-490   -> k_error / k_error_final
+//   closed-form derivatives           :1140-1549 -> k_jac_points (point-major) + k_jac_frames (frame-major)
+//   reduced camera system (Schur)     :1771-1908 -> k_schur + k_assemble
+//   point back-substitution + apply   :1919-1960, :1997-2017 -> k_backsub_obs + k_point_update
+//   camera apply (Rodrigues)          :2021-2062, :59-92     -> k_cam_apply
+// All arithmetic is fp64 (reference Scalar = double).  These kernels are HBM-bound streaming passes over the
+// observation arrays: every global access is lane-contiguous (SoA blocks), per-landmark sums are wavefront
+// segmented reductions, per-frame sums are register accumulators + wavefront reductions + one atomic per block.
+#include "srk_dev.hpp"
+
+#define WAVE 64
+
+__device__ __forceinline__ bool srk_is_fixed_var(int64_t var, int comp)
+{
+    // bundle-adj-kanatani.cpp:539-563: frame-local 4..9 of frame 0 and 14+comp are removed by the gauge
+    return (var >= 4 && var <= 9) || (var == 14 + comp);
+}
+
+// ------------------------------------------------------------------ camera pack
+__global__ void k_cam_pack(int32_t M, const double* __restrict__ R, const double* __restrict__ T,
+                           const double* __restrict__ K, double f0, double* __restrict__ pack)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double* r = R + 9 * (int64_t)j;
+    const double* t = T + 3 * (int64_t)j;
+    const double* k = K + 9 * (int64_t)j;
+    double* p = pack + (int64_t)SRK_CAM_PACK * j;
+    for (int i = 0; i < 9; ++i) { p[i] = r[i]; p[12 + i] = k[i]; }
+    for (int i = 0; i < 3; ++i) p[9 + i] = t[i];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) p[21 + 3 * a + b] = k[3 * a] * r[b] + k[3 * a + 1] * r[3 + b] + k[3 * a + 2] * r[6 + b];
+    // direct pose: Rd = R^T, Td = -(Rd T)   (obs-geom.cpp:117-122)
+    double td[3];
+    for (int c = 0; c < 3; ++c) td[c] = -(r[c] * t[0] + r[3 + c] * t[1] + r[6 + c] * t[2]);
+    double fx = k[0], fy = k[4], u0 = k[2], v0 = k[5];
+    for (int c = 0; c < 3; ++c) {
+        p[30 + c] = td[c];
+        // Rd[c][0] = R[0][c] etc.
+        p[33 + c] = fx * r[c] + u0 * r[6 + c];
+        p[36 + c] = fy * r[3 + c] + v0 * r[6 + c];
+        p[39 + c] = f0 * r[6 + c];
+    }
+    p[42] = 1 / fx;
+    p[43] = u0 / (f0 * fx);
+    p[44] = 1 / fy;
+    p[45] = v0 / (f0 * fy);
+    p[46] = 1 / f0;
+    p[47] = f0;
+}
+
+void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double* T, const double* K, double f0,
+                         double* pack)
+{
+    hipLaunchKernelGGL(k_cam_pack, dim3((M + 63) / 64), dim3(64), 0, s, M, R, T, K, f0, pack);
+}
+
+// ------------------------------------------------------------------ per-observation geometry
+struct ObsGeom {
+    double p, q, r;
+    double ex, ey;    // p/r - u/f0 , q/r - v/f0
+    double s1, s2;    // 2/r^2 , 2/r^4
+};
+
+__device__ __forceinline__ void obs_pqr(const double* __restrict__ c, double X0, double X1, double X2, double u,
+                                        double v, ObsGeom& g)
+{
+    double xc0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+    double xc1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+    double xc2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+    g.p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
+    g.q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
+    g.r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
+    double f0 = c[47];
+    g.ex = g.p / g.r - u / f0;
+    g.ey = g.q / g.r - v / f0;
+    double r2 = g.r * g.r;
+    g.s1 = 2 / r2;
+    g.s2 = 2 / (r2 * g.r * g.r);
+}
+
+// A_v = r p'_v - p r'_v , B_v = r q'_v - q r'_v for the three landmark variables (:1450-1455)
+__device__ __forceinline__ void point_ab(const double* __restrict__ c, const ObsGeom& g, double A[3], double B[3])
+{
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        double gp = c[21 + v], gq = c[24 + v], gr = c[27 + v];
+        A[v] = g.r * gp - g.p * gr;
+        B[v] = g.r * gq - g.q * gr;
+    }
+}
+
+// the ten frame variables [fx fy u0 v0 Tx Ty Tz Wx Wy Wz] (:1457-1525)
+__device__ __forceinline__ void frame_ab(const double* __restrict__ c, const ObsGeom& g, double X0, double X1,
+                                         double X2, double A[10], double B[10])
+{
+    double gp_fx = c[42] * g.p - c[43] * g.r;
+    double gq_fy = c[44] * g.q - c[45] * g.r;
+    double g_uv = c[46] * g.r;
+    A[0] = g.r * gp_fx; B[0] = 0;
+    A[1] = 0;           B[1] = g.r * gq_fy;
+    A[2] = g.r * g_uv;  B[2] = 0;
+    A[3] = 0;           B[3] = g.r * g_uv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double gp = -c[33 + k], gq = -c[36 + k], gr = -c[39 + k];
+        A[4 + k] = g.r * gp - g.p * gr;
+        B[4 + k] = g.r * gq - g.q * gr;
+    }
+    double t0 = X0 - c[30], t1 = X1 - c[31], t2 = X2 - c[32];
+    // cross(rot, t)
+    double cp[3], cq[3], cr[3];
+    cp[0] = c[34] * t2 - c[35] * t1; cp[1] = c[35] * t0 - c[33] * t2; cp[2] = c[33] * t1 - c[34] * t0;
+    cq[0] = c[37] * t2 - c[38] * t1; cq[1] = c[38] * t0 - c[36] * t2; cq[2] = c[36] * t1 - c[37] * t0;
+    cr[0] = c[40] * t2 - c[41] * t1; cr[1] = c[41] * t0 - c[39] * t2; cr[2] = c[39] * t1 - c[40] * t0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        A[7 + k] = g.r * cp[k] - g.p * cr[k];
+        B[7 + k] = g.r * cq[k] - g.q * cr[k];
+    }
+}
+
+// ------------------------------------------------------------------ K2a: point-major Jacobian pass
+// One thread per observation.  Writes the 3x10 point-frame block (SoA, lane-contiguous 8-byte stores) and
+// reduces the point block V (6 unique) + point gradient (3) over the landmark's observations with a
+// wavefront segmented reduction; one atomic per (wave, landmark) segment.
+__global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __restrict__ pts,
+                                                    const double* __restrict__ cam,
+                                                    const int32_t* __restrict__ obs_frame,
+                                                    const int32_t* __restrict__ obs_pt,
+                                                    const double* __restrict__ obs_uv, double* __restrict__ W,
+                                                    double* __restrict__ Vg)
+{
+    int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int lane = threadIdx.x & (WAVE - 1);
+    bool valid = o < d.O;
+    int32_t pt = -1;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0;
+    if (valid) {
+        pt = obs_pt[o];
+        int32_t j = obs_frame[o];
+        double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
+        const double* X = pts + 3 * (int64_t)pt;
+        double X0 = X[0], X1 = X[1], X2 = X[2];
+        const double* c = cam + (int64_t)SRK_CAM_PACK * j;
+        ObsGeom g;
+        obs_pqr(c, X0, X1, X2, uv.x, uv.y, g);
+        double Ap[3], Bp[3], Af[10], Bf[10];
+        point_ab(c, g, Ap, Bp);
+        frame_ab(c, g, X0, X1, X2, Af, Bf);
+#pragma unroll
+        for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+            for (int fv = 0; fv < 10; ++fv)
+                W[(int64_t)(10 * pv + fv) * d.Os + o] = (Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]) * g.s2;
+        acc[0] = (Ap[0] * Ap[0] + Bp[0] * Bp[0]) * g.s2;
+        acc[1] = (Ap[0] * Ap[1] + Bp[0] * Bp[1]) * g.s2;
+        acc[2] = (Ap[0] * Ap[2] + Bp[0] * Bp[2]) * g.s2;
+        acc[3] = (Ap[1] * Ap[1] + Bp[1] * Bp[1]) * g.s2;
+        acc[4] = (Ap[1] * Ap[2] + Bp[1] * Bp[2]) * g.s2;
+        acc[5] = (Ap[2] * Ap[2] + Bp[2] * Bp[2]) * g.s2;
+        acc[6] = (g.ex * Ap[0] + g.ey * Bp[0]) * g.s1;
+        acc[7] = (g.ex * Ap[1] + g.ey * Bp[1]) * g.s1;
+        acc[8] = (g.ex * Ap[2] + g.ey * Bp[2]) * g.s1;
+    }
+    // segmented (by landmark) suffix sums inside the wave: observations of one landmark are contiguous
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        int32_t okey = __shfl_down(pt, off, WAVE);
+        bool take = (lane + off < WAVE) && (okey == pt);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            double other = __shfl_down(acc[k], off, WAVE);
+            if (take) acc[k] += other;
+        }
+    }
+    int32_t prev = __shfl_up(pt, 1, WAVE);
+    bool head = (lane == 0) || (prev != pt);
+    if (head && pt >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(&Vg[(int64_t)k * d.Ns + pt], acc[k]);
+    }
+}
+
+void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
+                           const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
+                           double* Vg)
+{
+    if (d.O == 0) return;
+    int64_t blocks = (d.O + 255) / 256;
+    hipLaunchKernelGGL(k_jac_points, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
+                       W, Vg);
+}
+
+// ------------------------------------------------------------------ K2b: frame-major Jacobian pass
+// blockIdx.y = frame, blockIdx.x = chunk of SRK_FCHUNK observations of that frame.  Each thread keeps the 55
+// unique entries of the 10x10 frame block + the 10 gradient entries in registers, then wave-reduces.
+#define SRK_FCHUNK 1024
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_jac_frames(SrkDims d, const double* __restrict__ pts,
+                                                    const double* __restrict__ cam,
+                                                    const int64_t* __restrict__ col_ptr,
+                                                    const int32_t* __restrict__ fobs_pt,
+                                                    const double* __restrict__ fobs_uv, double* __restrict__ Ug)
+{
+    __shared__ double red[4][SRK_UG];
+    int j = blockIdx.y;
+    int64_t begin = col_ptr[j] + (int64_t)blockIdx.x * SRK_FCHUNK;
+    int64_t end = col_ptr[j + 1];
+    if (begin >= end) return;
+    if (end > begin + SRK_FCHUNK) end = begin + SRK_FCHUNK;
+    const double* c = cam + (int64_t)SRK_CAM_PACK * j;
+    double acc[SRK_UG];
+#pragma unroll
+    for (int k = 0; k < SRK_UG; ++k) acc[k] = 0;
+    for (int64_t k = begin + threadIdx.x; k < end; k += 256) {
+        int32_t pt = fobs_pt[k];
+        double2 uv = reinterpret_cast<const double2*>(fobs_uv)[k];
+        const double* X = pts + 3 * (int64_t)pt;
+        double X0 = X[0], X1 = X[1], X2 = X[2];
+        ObsGeom g;
+        obs_pqr(c, X0, X1, X2, uv.x, uv.y, g);
+        double Af[10], Bf[10];
+        frame_ab(c, g, X0, X1, X2, Af, Bf);
+        int idx = 0;
+#pragma unroll
+        for (int v1 = 0; v1 < 10; ++v1)
+#pragma unroll
+            for (int v2 = v1; v2 < 10; ++v2) {
+                acc[idx] += (Af[v1] * Af[v2] + Bf[v1] * Bf[v2]) * g.s2;
+                ++idx;
+            }
+#pragma unroll
+        for (int v = 0; v < 10; ++v) acc[55 + v] += (g.ex * Af[v] + g.ey * Bf[v]) * g.s1;
+    }
+    int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < SRK_UG; ++k) {
+        double v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < SRK_UG) {
+        double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(&Ug[(int64_t)j * SRK_UG + threadIdx.x], v);
+    }
+}
+
+void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_obs, const double* pts,
+                           const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
+                           double* Ug)
+{
+    if (d.O == 0 || max_frame_obs == 0) return;
+    int64_t chunks = (max_frame_obs + SRK_FCHUNK - 1) / SRK_FCHUNK;
+    hipLaunchKernelGGL(k_jac_frames, dim3((unsigned)chunks, (unsigned)d.M), dim3(256), 0, s, d, pts, cam, col_ptr,
+                       fobs_pt, fobs_uv, Ug);
+}
+
+// expand the packed per-frame accumulators to the oracle's [M][10][10] + [M][10] layout (tests / downloads)
+__global__ void k_expand_ug(int32_t M, const double* __restrict__ Ug, double* __restrict__ U, double* __restrict__ gf)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * 110) return;
+    int j = t / 110, e = t % 110;
+    const double* u = Ug + (int64_t)j * SRK_UG;
+    if (e < 100) {
+        int v1 = e / 10, v2 = e % 10;
+        int a = v1 < v2 ? v1 : v2, b = v1 < v2 ? v2 : v1;
+        int idx = a * 10 - a * (a - 1) / 2 + (b - a);
+        U[(int64_t)j * 100 + e] = u[idx];
+    } else {
+        gf[(int64_t)j * 10 + (e - 100)] = u[55 + (e - 100)];
+    }
+}
+void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full)
+{
+    int n = M * 110;
+    hipLaunchKernelGGL(k_expand_ug, dim3((n + 255) / 256), dim3(256), 0, s, M, Ug, U_full, g_full);
+}
+
+// ------------------------------------------------------------------ 3x3 damped point block inverse
+// E = V with diagonal * (1 + c) (:1825-1834); Eigen computeInverseAndDetWithCheck: invertible iff |det| > 1e-12
+__device__ __forceinline__ bool point_block_inverse(const double* __restrict__ Vg, int64_t Ns, int64_t pt, double c,
+                                                    double Einv[9], double g[3])
+{
+    double e00 = Vg[0 * Ns + pt] * (1 + c), e01 = Vg[1 * Ns + pt], e02 = Vg[2 * Ns + pt];
+    double e11 = Vg[3 * Ns + pt] * (1 + c), e12 = Vg[4 * Ns + pt], e22 = Vg[5 * Ns + pt] * (1 + c);
+    g[0] = Vg[6 * Ns + pt]; g[1] = Vg[7 * Ns + pt]; g[2] = Vg[8 * Ns + pt];
+    double c00 = e11 * e22 - e12 * e12;
+    double c01 = e12 * e02 - e01 * e22;
+    double c02 = e01 * e12 - e11 * e02;
+    double det = e00 * c00 + e01 * c01 + e02 * c02;
+    if (!(fabs(det) > 1e-12)) return false;
+    double id = 1 / det;
+    Einv[0] = c00 * id;
+    Einv[1] = (e02 * e12 - e01 * e22) * id;
+    Einv[2] = (e01 * e12 - e02 * e11) * id;
+    Einv[3] = c01 * id;
+    Einv[4] = (e00 * e22 - e02 * e02) * id;
+    Einv[5] = (e02 * e01 - e00 * e12) * id;
+    Einv[6] = c02 * id;
+    Einv[7] = (e01 * e02 - e00 * e12) * id;
+    Einv[8] = (e00 * e11 - e01 * e01) * id;
+    return true;
+}
+
+// ------------------------------------------------------------------ K3: Schur accumulation (per landmark)
+// One workgroup per landmark: 3x3 elimination block inverted in registers, W_i staged in LDS, Y = E^-1 W_i in LDS,
+// then the n_i(n_i+1)/2 lower 10x10 outer-product blocks are subtracted from S with fp64 atomics.
+#define SRK_SCH 32 // observations per LDS chunk
+
+__global__ __launch_bounds__(256) void k_schur(SrkDims d, double c, const int64_t* __restrict__ row_ptr,
+                                               const int32_t* __restrict__ obs_frame, const double* __restrict__ W,
+                                               const double* __restrict__ Vg, double* __restrict__ S,
+                                               double* __restrict__ rhs)
+{
+    __shared__ double sWa[SRK_SCH][30];
+    __shared__ double sYb[SRK_SCH][30];
+    __shared__ int32_t sFa[SRK_SCH], sFb[SRK_SCH];
+    for (int64_t pt = blockIdx.x; pt < d.N; pt += gridDim.x) {
+        double Einv[9], g[3];
+        bool ok = point_block_inverse(Vg, d.Ns, pt, c, Einv, g); // block-uniform
+        if (!ok) continue;                                        // :1877-1881 skip the landmark
+        double Eg[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) Eg[m] = Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2];
+        int64_t o0 = row_ptr[pt];
+        int n = (int)(row_ptr[pt + 1] - o0);
+        int nchunks = (n + SRK_SCH - 1) / SRK_SCH;
+        for (int ca = 0; ca < nchunks; ++ca) {
+            int a0 = ca * SRK_SCH;
+            int na = n - a0 < SRK_SCH ? n - a0 : SRK_SCH;
+            __syncthreads();
+            for (int t = threadIdx.x; t < na * 30; t += 256) {
+                int k = t / na, a = t - k * na;
+                sWa[a][k] = W[(int64_t)k * d.Os + o0 + a0 + a];
+            }
+            if (threadIdx.x < na) sFa[threadIdx.x] = obs_frame[o0 + a0 + threadIdx.x];
+            __syncthreads();
+            // rhs += F^T E^-1 g   (:1895-1897)
+            for (int t = threadIdx.x; t < na * 10; t += 256) {
+                int a = t / 10, r = t - a * 10;
+                int64_t row = 10 * (int64_t)sFa[a] + r;
+                if (!srk_is_fixed_var(row, d.comp)) {
+                    double v = sWa[a][r] * Eg[0] + sWa[a][10 + r] * Eg[1] + sWa[a][20 + r] * Eg[2];
+                    atomicAdd(&rhs[row], v);
+                }
+            }
+            for (int cb = 0; cb <= ca; ++cb) {
+                int b0 = cb * SRK_SCH;
+                int nb = n - b0 < SRK_SCH ? n - b0 : SRK_SCH;
+                __syncthreads();
+                for (int t = threadIdx.x; t < nb * 10; t += 256) {
+                    int fv = t / nb, b = t - fv * nb;
+                    int64_t ob = o0 + b0 + b;
+                    double w0 = W[(int64_t)fv * d.Os + ob], w1 = W[(int64_t)(10 + fv) * d.Os + ob],
+                           w2 = W[(int64_t)(20 + fv) * d.Os + ob];
+                    // Y = E^-1 W  (3 x 10)
+                    sYb[b][fv] = Einv[0] * w0 + Einv[1] * w1 + Einv[2] * w2;
+                    sYb[b][10 + fv] = Einv[3] * w0 + Einv[4] * w1 + Einv[5] * w2;
+                    sYb[b][20 + fv] = Einv[6] * w0 + Einv[7] * w1 + Einv[8] * w2;
+                }
+                if (threadIdx.x < nb) sFb[threadIdx.x] = obs_frame[o0 + b0 + threadIdx.x];
+                __syncthreads();
+                int total = na * nb * 100;
+                for (int t = threadIdx.x; t < total; t += 256) {
+                    int e = t % 100, pr = t / 100;
+                    int b = pr % nb, a = pr / nb;
+                    if (ca == cb && b > a) continue; // lower block triangle only (frames ascend inside a landmark)
+                    int r = e / 10, cc = e - r * 10;
+                    int64_t row = 10 * (int64_t)sFa[a] + r, col = 10 * (int64_t)sFb[b] + cc;
+                    if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
+                    double v = sWa[a][r] * sYb[b][cc] + sWa[a][10 + r] * sYb[b][10 + cc] + sWa[a][20 + r] * sYb[b][20 + cc];
+                    atomicAdd(&S[row * d.ld + col], -v); // S = G - sum F^T E^-1 F  (:1891-1892)
+                }
+            }
+        }
+    }
+}
+
+void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_frame,
+                      const double* W, const double* Vg, double* S, double* rhs)
+{
+    if (d.N == 0) return;
+    int64_t blocks = d.N < 65536 ? d.N : 65536;
+    hipLaunchKernelGGL(k_schur, dim3((unsigned)blocks), dim3(256), 0, s, d, c, row_ptr, obs_frame, W, Vg, S, rhs);
+}
+
+// G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark
+// sums; fixed variables and padding rows get an identity diagonal (:1780-1823, :1902-1908).
+__global__ void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, double* __restrict__ S,
+                           double* __restrict__ rhs)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nblk = (int64_t)d.M * 110;
+    if (t < nblk) {
+        int64_t j = t / 110;
+        int e = (int)(t - j * 110);
+        const double* u = Ug + j * SRK_UG;
+        if (e < 100) {
+            int v1 = e / 10, v2 = e - v1 * 10;
+            int64_t row = 10 * j + v1, col = 10 * j + v2;
+            bool fr = srk_is_fixed_var(row, d.comp), fc = srk_is_fixed_var(col, d.comp);
+            if (fr || fc) {
+                if (v1 == v2) S[row * d.ld + col] = 1.0;
+            } else {
+                int a = v1 < v2 ? v1 : v2, b = v1 < v2 ? v2 : v1;
+                double val = u[a * 10 - a * (a - 1) / 2 + (b - a)];
+                if (v1 == v2) val *= 1 + c;
+                S[row * d.ld + col] += val;
+            }
+        } else {
+            int v = e - 100;
+            int64_t row = 10 * j + v;
+            if (srk_is_fixed_var(row, d.comp)) rhs[row] = 0.0;
+            else rhs[row] -= u[55 + v];
+        }
+    } else {
+        int64_t p = 10 * (int64_t)d.M + (t - nblk);
+        if (p < d.ld) {
+            S[p * d.ld + p] = 1.0;
+            rhs[p] = 0.0;
+        }
+    }
+}
+
+void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs)
+{
+    int64_t n = (int64_t)d.M * 110 + (d.ld - 10 * (int64_t)d.M);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, c, Ug, S, rhs);
+}
+
+// mirror the lower triangle into the upper one (downloads / exchange of the full matrix)
+__global__ void k_symmetrize(int64_t n, int64_t ld, double* __restrict__ S)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t r = blockIdx.y;
+    if (c < n && r < n && c > r) S[r * ld + c] = S[c * ld + r];
+}
+void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S)
+{
+    hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s, n, ld, S);
+}
+
+// ------------------------------------------------------------------ K5: back-substitution + landmark update
+// thread per observation: t = W_ij dc_j (3-vector), segmented wave reduction by landmark, one atomic per segment
+__global__ __launch_bounds__(256) void k_backsub_obs(SrkDims d, const int32_t* __restrict__ obs_frame,
+                                                     const int32_t* __restrict__ obs_pt, const double* __restrict__ W,
+                                                     const double* __restrict__ dc, double* __restrict__ acc)
+{
+    int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int lane = threadIdx.x & (WAVE - 1);
+    int32_t pt = -1;
+    double t[3] = { 0, 0, 0 };
+    if (o < d.O) {
+        pt = obs_pt[o];
+        const double* x = dc + 10 * (int64_t)obs_frame[o];
+        double xv[10];
+#pragma unroll
+        for (int fv = 0; fv < 10; ++fv) xv[fv] = x[fv];
+#pragma unroll
+        for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+            for (int fv = 0; fv < 10; ++fv) t[pv] += W[(int64_t)(10 * pv + fv) * d.Os + o] * xv[fv];
+    }
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        int32_t okey = __shfl_down(pt, off, WAVE);
+        bool take = (lane + off < WAVE) && (okey == pt);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double other = __shfl_down(t[k], off, WAVE);
+            if (take) t[k] += other;
+        }
+    }
+    int32_t prev = __shfl_up(pt, 1, WAVE);
+    bool head = (lane == 0) || (prev != pt);
+    if (head && pt >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(&acc[(int64_t)k * d.Ns + pt], t[k]);
+    }
+}
+
+// dx_i = -E^-1 (F_i dc + g_i)  (:1951), zero when E is not invertible (:1939-1943); X_trial = X + dx (:2012-2016)
+__global__ void k_point_update(SrkDims d, double c, const double* __restrict__ Vg, const double* __restrict__ acc,
+                               const double* __restrict__ pts, double* __restrict__ pts_trial, double* __restrict__ dx,
+                               int* __restrict__ info)
+{
+    int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= d.N) return;
+    double Einv[9], g[3];
+    double dxi[3] = { 0, 0, 0 };
+    if (point_block_inverse(Vg, d.Ns, pt, c, Einv, g)) {
+        double b0 = acc[pt] + g[0], b1 = acc[d.Ns + pt] + g[1], b2 = acc[2 * d.Ns + pt] + g[2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            dxi[m] = -(Einv[3 * m] * b0 + Einv[3 * m + 1] * b1 + Einv[3 * m + 2] * b2);
+            if (!isfinite(dxi[m])) atomicOr(info, 2); // :1953-1954
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        dx[3 * pt + m] = dxi[m];
+        pts_trial[3 * pt + m] = pts[3 * pt + m] + dxi[m];
+    }
+}
+
+void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,
+                        const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
+                        double* pts_trial, double* dx)
+{
+    // acc is zeroed by the caller (hipMemsetAsync) and the info word is the int right behind acc
+    if (d.O > 0) {
+        int64_t blocks = (d.O + 255) / 256;
+        hipLaunchKernelGGL(k_backsub_obs, dim3((unsigned)blocks), dim3(256), 0, s, d, obs_frame, obs_pt, W, dc, acc);
+    }
+    if (d.N > 0) {
+        int* info = reinterpret_cast<int*>(acc + 3 * d.Ns);
+        hipLaunchKernelGGL(k_point_update, dim3((unsigned)((d.N + 255) / 256)), dim3(256), 0, s, d, c, Vg, acc, pts,
+                           pts_trial, dx, info);
+    }
+}
+
+// ------------------------------------------------------------------ K6: camera update
+// T_direct += dT ; R_direct <- Rodrigues(dW) R_direct unless |dW| ~ 0 ; store the inverse pose (:2021-2062, :59-92)
+__global__ void k_cam_apply(int32_t M, const double* __restrict__ R, const double* __restrict__ T,
+                            const double* __restrict__ dc, double* __restrict__ Rn, double* __restrict__ Tn)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double* r = R + 9 * (int64_t)j;
+    const double* t = T + 3 * (int64_t)j;
+    const double* x = dc + 10 * (int64_t)j;
+    double Rd[9], Td[3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Rd[3 * a + b] = r[3 * b + a];
+    for (int a = 0; a < 3; ++a) Td[a] = -(Rd[3 * a] * t[0] + Rd[3 * a + 1] * t[1] + Rd[3 * a + 2] * t[2]);
+    Td[0] += x[4]; Td[1] += x[5]; Td[2] += x[6];
+    double w0 = x[7], w1 = x[8], w2 = x[9];
+    double ang = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    double Rnew[9];
+    // IsClose(0, ang): |ang| <= 1e-8 + 1e-5 * |max(0, ang)|  (approx-alg.h:8-16, obs-geom.cpp:555-556)
+    bool zero = fabs(0.0 - ang) <= (1.0e-8 + 1.0e-5 * fabs(ang > 0.0 ? ang : 0.0));
+    if (zero) {
+        for (int i = 0; i < 9; ++i) Rnew[i] = Rd[i];
+    } else {
+        double d0 = w0 / ang, d1 = w1 / ang, d2 = w2 / ang;
+        double sn = sin(ang), cs = cos(ang);
+        double Kx[9] = { 0, -d2, d1, d2, 0, -d0, -d1, d0, 0 };
+        double KK[9], rot[9];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                KK[3 * a + b] = Kx[3 * a] * Kx[b] + Kx[3 * a + 1] * Kx[3 + b] + Kx[3 * a + 2] * Kx[6 + b];
+        for (int i = 0; i < 9; ++i) rot[i] = ((i == 0 || i == 4 || i == 8) ? 1.0 : 0.0) + sn * Kx[i] + (1 - cs) * KK[i];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                Rnew[3 * a + b] = rot[3 * a] * Rd[b] + rot[3 * a + 1] * Rd[3 + b] + rot[3 * a + 2] * Rd[6 + b];
+    }
+    double* ro = Rn + 9 * (int64_t)j;
+    double* to = Tn + 3 * (int64_t)j;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) ro[3 * a + b] = Rnew[3 * b + a];
+    for (int a = 0; a < 3; ++a) to[a] = -(ro[3 * a] * Td[0] + ro[3 * a + 1] * Td[1] + ro[3 * a + 2] * Td[2]);
+}
+
+void srk_launch_cam_apply(hipStream_t s, int32_t M, const double* R, const double* T, const double* dc, double* Rn,
+                          double* Tn)
+{
+    hipLaunchKernelGGL(k_cam_apply, dim3((M + 63) / 64), dim3(64), 0, s, M, R, T, dc, Rn, Tn);
+}
+
+// ------------------------------------------------------------------ K1: reprojection error
+#define SRK_ERR_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void k_error(SrkDims d, const double* __restrict__ pts,
+                                               const double* __restrict__ cam, const int32_t* __restrict__ obs_frame,
+                                               const int32_t* __restrict__ obs_pt, const double* __restrict__ obs_uv,
+                                               double* __restrict__ partial)
+{
+    __shared__ double red[4];
+    double sum = 0;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < d.O; o += (int64_t)gridDim.x * 256) {
+        int32_t pt = obs_pt[o];
+        const double* c = cam + (int64_t)SRK_CAM_PACK * obs_frame[o];
+        double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
+        const double* X = pts + 3 * (int64_t)pt;
+        double X0 = X[0], X1 = X[1], X2 = X[2];
+        double xc0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+        double xc1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+        double xc2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+        double p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
+        double q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
+        double r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
+        double f0 = c[47];
+        double ex = p / r - uv.x / f0, ey = q / r - uv.y / f0;
+        sum += ex * ex + ey * ey;
+    }
+    sum = wave_sum(sum);
+    int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// fixed-order final sum: the LM accept/reject decision must not depend on atomic arrival order
+__global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __restrict__ partial,
+                                                     double* __restrict__ out)
+{
+    __shared__ double red[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+int32_t srk_error_partials(const SrkDims& d)
+{
+    int64_t blocks = (d.O + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    return (int32_t)(blocks < SRK_ERR_BLOCKS ? blocks : SRK_ERR_BLOCKS);
+}
+
+void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
+                      const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
+                      int32_t n_partial, double* err_out)
+{
+    hipLaunchKernelGGL(k_error, dim3((unsigned)n_partial), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
+                       partial);
+    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, err_out);
+}

@@ -1,0 +1,62 @@
+// srk_dev.hpp -- internal declarations shared by the HIP translation units of libsrk_ba.so.
+// Device data layout (all fp64 unless noted; see DESIGN.md "Data layout in HBM"):
+//   pts      [N][3]            landmark coordinates (normalised world), two buffers: current / trial
+//   cam      [M][SRK_CAM_PACK] per-frame pack recomputed from (R,T,K) once per pose change:
+//              0-8 R  9-11 T  12-20 K  21-29 K*R  30-32 Td (direct translation)
+//              33-35 rot1  36-38 rot2  39-41 rot3  (bundle-adj-kanatani.cpp:1511-1513)
+//              42 1/fx  43 u0/(f0 fx)  44 1/fy  45 v0/(f0 fy)  46 1/f0  47 f0
+//   obs      point-major CSR: row_ptr[N+1] i64, obs_frame[O] i32, obs_pt[O] i32, obs_uv[O][2]
+//            frame-major copy:  col_ptr[M+1] i64, fobs_pt[O] i32, fobs_uv[O][2]
+//   W        [30][Os]  point-frame blocks, structure-of-arrays: element k = 10*pv + fv of observation o
+//            lives at W[k*Os + o] (Os = O rounded up to 64) -> every store/load is lane-contiguous
+//   Vg       [9][Ns]   per point: V00 V01 V02 V11 V12 V22 g0 g1 g2 (SoA, Ns = N rounded up to 64)
+//   Ug       [M][65]   per frame: 55 upper-triangle entries of the 10x10 block (row-major order) + 10 gradient
+//   S        [ld][ld]  padded reduced camera system, row-major, LOWER triangle authoritative;
+//            variable index = 10*frame + var; the 7 gauge-fixed variables and the padding rows
+//            carry an identity diagonal and zero rhs, so their correction is exactly 0
+//   rhs,dc   [ld]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SRK_CAM_PACK 48
+#define SRK_UG 65
+
+struct SrkDims {
+    int64_t N, O, Os, Ns;
+    int32_t M;
+    int64_t ld;          // padded RCS dimension (multiple of SRK_CHOL_NB)
+    int32_t comp;        // unity_t1_comp_ind (gauge), 1 by default
+};
+
+#define SRK_CHOL_NB 64
+
+// ---- BA kernels (srk_ba_kernels.hip) ----
+void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double* T, const double* K, double f0,
+                         double* pack);
+void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
+                           const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
+                           double* Vg);
+void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_obs, const double* pts,
+                           const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
+                           double* Ug);
+void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_frame,
+                      const double* W, const double* Vg, double* S, double* rhs);
+void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs);
+void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,
+                        const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
+                        double* pts_trial, double* dx);
+void srk_launch_cam_apply(hipStream_t s, int32_t M, const double* R, const double* T, const double* dc, double* Rn,
+                          double* Tn);
+void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
+                      const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
+                      int32_t n_partial, double* err_out);
+int32_t srk_error_partials(const SrkDims& d);
+void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full);
+void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
+
+// ---- dense SPD solver (srk_chol.hip) ----
+// In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) followed by
+// forward/backward substitution of b into x.  info (device int) is set non-zero when a pivot is not positive/finite.
+void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
+                    hipEvent_t* ev_pairs /* 2 * (ld / SRK_CHOL_NB) events or NULL */);

@@ -1,0 +1,68 @@
+"""Synthetic circle-grid scenes through the C ABI (srk_scene_generate, surikatoko_amd/csrc/srk_scene.cpp),
+restating cpp_impl/demos/demo-bundle-adj-circle-grid.cpp:86-257 of the reference."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import SceneSpecC, lib
+
+
+@dataclass
+class SceneSpec:
+    n_frames: int
+    grid_nx: int
+    grid_ny: int
+    vis_window: int = 20
+    half_extent_x: float = 1.0
+    half_extent_y: float = 1.0
+    f0: float = 600.0
+    noise_x3d_hi: float = 0.005
+    noise_r_hi: float = 0.005
+    noise_uv_pix: float = 0.0
+    seed: int = 1234
+
+    def to_c(self):
+        return SceneSpecC(self.n_frames, self.grid_nx, self.grid_ny, self.vis_window, self.half_extent_x,
+                          self.half_extent_y, self.f0, self.noise_x3d_hi, self.noise_r_hi, self.noise_uv_pix,
+                          self.seed)
+
+
+# BASELINE.json configs (SURVEY 8d grid sizes); C1 is the labelled synthetic stand-in for the missing dino files
+CONFIGS = {
+    "C1_dino_standin": SceneSpec(36, 53, 94, vis_window=3),          # 36 cams, 4982 pts, 14946 obs
+    "C2_200cam_20kpt": SceneSpec(200, 200, 100, vis_window=20),      # 400k obs
+    "C3_1kcam_100kpt": SceneSpec(1000, 400, 250, vis_window=20),     # 2M obs (headline)
+    "C5_4kcam_1Mpt": SceneSpec(4000, 1000, 1000, vis_window=20),     # 20M obs
+    "demo_circle_grid": SceneSpec(36, 5, 5, vis_window=0),           # the demo's own 36-frame all-visible scene
+}
+
+
+def generate_scene(spec: SceneSpec, with_gt=False):
+    """Returns a surikatoko_amd.ba.Scene (and the ground truth arrays when with_gt)."""
+    from .ba import Scene
+    L = lib()
+    cs = spec.to_c()
+    O = L.srk_scene_num_observations(C.byref(cs))
+    if O < 0:
+        raise ValueError("bad scene spec")
+    N, M = spec.grid_nx * spec.grid_ny, spec.n_frames
+    pts = np.zeros((N, 3))
+    pts_gt = np.zeros((N, 3))
+    R = np.zeros((M, 9))
+    T = np.zeros((M, 3))
+    Rg = np.zeros((M, 9))
+    Tg = np.zeros((M, 3))
+    K = np.zeros((M, 9))
+    row_ptr = np.zeros(N + 1, dtype=np.int64)
+    obs_frame = np.zeros(O, dtype=np.int32)
+    obs_uv = np.zeros((O, 2))
+    dp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = L.srk_scene_generate(C.byref(cs), dp(pts), dp(pts_gt), dp(R), dp(T), dp(Rg), dp(Tg), dp(K), dp(row_ptr),
+                              dp(obs_frame), dp(obs_uv))
+    if rc != 0:
+        raise RuntimeError(f"srk_scene_generate failed: {rc}")
+    sc = Scene(pts, R, T, K, False, row_ptr, obs_frame, obs_uv)
+    if with_gt:
+        return sc, pts_gt, Rg, Tg
+    return sc

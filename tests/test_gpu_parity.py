@@ -1,0 +1,309 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (fp64): per-element blocks rel 1e-12 of the block scale; reduced camera system and rhs
+rel 1e-10 (reordered sums, fp64 atomics); one-step corrections rel 1e-8 (Cholesky vs Householder QR);
+end-to-end: same accept/reject sequence, final error rel 1e-6, scene abs 1e-6 in normalised units.
+"""
+import numpy as np
+import pytest
+
+import surikatoko_amd as sa
+from surikatoko_amd import ba as B
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    h = sa.BundleAdjustmentKanatani(0)
+    yield h
+    h.close()
+
+
+def _orc_scene(orc, sc):
+    return orc.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, sc.row_ptr, sc.obs_frame, sc.obs_uv)
+
+
+def _golden_scene(name):
+    g = load_golden(name)
+    return sa.Scene(g["in_points"], g["in_cam_R"], g["in_cam_T"], g["in_K"], 0, g["in_row_ptr"], g["in_obs_frame"],
+                    g["in_obs_uv"]), float(g["f0"]), g
+
+
+def _reduced_index(M, comp=1):
+    """full frame variable -> reduced index (or -1), bundle-adj-kanatani.cpp:539-563."""
+    red = np.full(10 * M, -1, dtype=np.int64)
+    r = 0
+    for fi in range(10 * M):
+        if 4 <= fi <= 9 or fi == 14 + comp:
+            continue
+        red[fi] = r
+        r += 1
+    return red
+
+
+SCENES = {
+    "tiny": sa.SceneSpec(n_frames=5, grid_nx=4, grid_ny=3, vis_window=3),
+    "all_visible": sa.SceneSpec(n_frames=8, grid_nx=5, grid_ny=5, vis_window=0),       # the demo's visibility
+    "ragged_wave": sa.SceneSpec(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7),    # segments straddle waves
+    "long_tracks": sa.SceneSpec(n_frames=90, grid_nx=6, grid_ny=5, vis_window=80),     # > one LDS chunk per landmark
+    "pixel_noise": sa.SceneSpec(n_frames=12, grid_nx=10, grid_ny=10, vis_window=5, noise_uv_pix=0.5),
+}
+
+
+def _phases(orc, gpu, sc, f0, c, already_normalized=False):
+    """Run derivatives -> schur -> solve -> backsub on both sides; return both sets of intermediates."""
+    so = _orc_scene(orc, sc)
+    if not already_normalized:
+        ok, _ = orc.normalize(so)
+        assert ok
+    assert gpu.upload(f0, sc, already_normalized=already_normalized)
+    out = {}
+    out["err_o"], out["seen_o"] = orc.reproj_error(f0, so)
+    out["err_g"], out["seen_g"] = gpu.phase_error()
+    gradE, V, U, W = orc.derivatives(f0, so)
+    gpu.phase_derivatives()
+    out.update(gradE_o=gradE, V_o=V, U_o=U, W_o=W, gradE_g=gpu.buffer(B.BUF_GRAD),
+               V_g=gpu.buffer(B.BUF_POINT_BLOCKS).reshape(-1, 3, 3), U_g=gpu.buffer(B.BUF_FRAME_BLOCKS).reshape(-1, 10, 10),
+               W_g=gpu.buffer(B.BUF_POINT_FRAME).reshape(-1, 3, 10))
+    ok, corr, S, rhs = orc.two_phase(so, gradE, V, U, W, c, want_system=True)
+    gpu.phase_schur(c)
+    M = sc.M
+    Sg = gpu.buffer(B.BUF_RCS).reshape(10 * M, 10 * M)
+    rg = gpu.buffer(B.BUF_RCS_RHS)
+    out.update(ok_o=ok, corr_o=corr, S_o=S, rhs_o=rhs, S_g=Sg, rhs_g=rg)
+    out["ok_g"] = gpu.phase_solve()
+    gpu.phase_backsub(c)
+    out["corr_g"] = gpu.buffer(B.BUF_CORRECTIONS)
+    orc.apply_corrections(so, corr)
+    gpu.phase_accept()
+    out.update(pts_o=so.points, R_o=so.cam_R, T_o=so.cam_T, pts_g=gpu.buffer(B.BUF_POINTS).reshape(-1, 3),
+               R_g=gpu.buffer(B.BUF_CAM_R).reshape(-1, 9), T_g=gpu.buffer(B.BUF_CAM_T).reshape(-1, 3))
+    out["err2_o"], _ = orc.reproj_error(f0, so)
+    out["err2_g"], _ = gpu.phase_error()
+    return out
+
+
+def _check(out, M, corr_tol=1e-8):
+    assert out["seen_g"] == out["seen_o"]
+    assert out["err_g"] == pytest.approx(out["err_o"], rel=1e-12)
+    assert rel_err(out["V_g"], out["V_o"]) < 1e-12
+    assert rel_err(out["W_g"], out["W_o"]) < 1e-12
+    assert rel_err(out["U_g"], out["U_o"]) < 1e-12
+    assert rel_err(out["gradE_g"], out["gradE_o"]) < 1e-10  # sums with cancellation
+    red = _reduced_index(M)
+    keep = red >= 0
+    Sg = out["S_g"][np.ix_(keep, keep)]
+    assert rel_err(Sg, out["S_o"]) < 1e-10
+    assert rel_err(out["rhs_g"][keep], out["rhs_o"]) < 1e-10
+    # gauge-fixed variables: identity rows, zero rhs
+    fixed = np.where(~keep)[0]
+    for f in fixed:
+        row = out["S_g"][f].copy()
+        assert row[f] == 1.0
+        row[f] = 0
+        assert np.all(row == 0) and out["rhs_g"][f] == 0
+    assert out["ok_g"] and out["ok_o"]
+    assert rel_err(out["corr_g"], out["corr_o"]) < corr_tol
+    N3 = len(out["corr_g"]) - 10 * M
+    fr = out["corr_g"][N3:]
+    assert np.all(fr[4:10] == 0) and fr[15] == 0  # exact zero gaps (:1618-1654)
+    scale = max(1.0, float(np.abs(out["pts_o"]).max()))
+    assert np.abs(out["pts_g"] - out["pts_o"]).max() < 1e-8 * scale
+    assert np.abs(out["R_g"] - out["R_o"]).max() < 1e-8
+    assert np.abs(out["T_g"] - out["T_o"]).max() < 1e-8 * scale
+    assert out["err2_g"] == pytest.approx(out["err2_o"], rel=1e-6)
+
+
+# ------------------------------------------------------------------ kernels one by one
+
+def test_dense_spd_solve_mfma(gpu):
+    """blocked Cholesky with the fp64 MFMA trailing update vs numpy; checks the f64 16x16x4 accumulator map."""
+    rng = np.random.RandomState(3)
+    for n in (1, 7, 64, 65, 130, 200, 513):
+        A = rng.randn(n, n)
+        A = A @ A.T + n * np.eye(n)
+        A += np.diag(np.arange(n) * 0.37)  # asymmetric-looking spectrum: a transposed tile map would show
+        b = rng.randn(n)
+        ok, x, _ = gpu.dense_spd_solve(A, b)
+        assert ok
+        assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
+
+
+def test_dense_spd_solve_rejects_indefinite(gpu):
+    A = np.eye(70)
+    A[40, 40] = -1.0
+    ok, _, _ = gpu.dense_spd_solve(A, np.ones(70))
+    assert not ok
+
+
+@pytest.mark.parametrize("case", ["pyproto_case_a", "pyproto_case_b"])
+@pytest.mark.parametrize("c", [1e-4, 1e-1])
+def test_phases_on_golden_inputs(orc, gpu, case, c):
+    sc, f0, g = _golden_scene(case)
+    out = _phases(orc, gpu, sc, f0, c)
+    _check(out, sc.M, corr_tol=1e-6 if c < 1e-3 else 1e-8)
+    # and against the Python prototype's own numbers (committed golden fixtures)
+    N, M = sc.N, sc.M
+    assert rel_err(out["V_g"].reshape(3 * N, 3), g["deriv_second_point"]) < 1e-12
+    assert rel_err(out["U_g"].reshape(10 * M, 10), g["deriv_second_frame"]) < 1e-12
+    assert rel_err(out["gradE_g"], g["gradE"]) < 1e-10
+    tag = {1e-4: "c1e-4", 1e-1: "c1e-1"}[c]
+    assert rel_err(out["corr_g"], g["corrections_" + tag]) < (1e-6 if c < 1e-3 else 1e-8)
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+@pytest.mark.parametrize("c", [1e-4, 10.0])
+def test_phases_on_synthetic_scenes(orc, gpu, name, c):
+    sc = sa.generate_scene(SCENES[name])
+    out = _phases(orc, gpu, sc, SCENES[name].f0, c)
+    _check(out, sc.M, corr_tol=1e-7)
+
+
+def test_single_observation_points_are_skipped(orc, gpu):
+    """A landmark seen once has a rank-2 point block: |det| <= 1e-12 -> skipped in the Schur sum, zero correction
+    (bundle-adj-kanatani.cpp:1876-1881, 1939-1943)."""
+    sc = sa.generate_scene(sa.SceneSpec(n_frames=6, grid_nx=5, grid_ny=4, vis_window=3))
+    # cut the tracks of three landmarks down to one observation
+    keep = np.ones(sc.O, dtype=bool)
+    for i in (0, 7, 19):
+        keep[sc.row_ptr[i] + 1:sc.row_ptr[i + 1]] = False
+    counts = np.array([keep[sc.row_ptr[i]:sc.row_ptr[i + 1]].sum() for i in range(sc.N)])
+    sc2 = sa.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, 0, np.concatenate([[0], np.cumsum(counts)]),
+                   sc.obs_frame[keep], sc.obs_uv[keep])
+    out = _phases(orc, gpu, sc2, 600.0, 1e-4)
+    _check(out, sc2.M, corr_tol=1e-7)
+    for i in (0, 7, 19):
+        assert np.all(out["corr_g"][3 * i:3 * i + 3] == 0)
+        assert np.all(out["corr_o"][3 * i:3 * i + 3] == 0)
+
+
+def test_shared_k_mode(orc, gpu):
+    """multi-view-factorization call contract: shared K, f0 = 1 (multi-view-factorization.cpp:387-391)."""
+    sc = sa.generate_scene(sa.SceneSpec(n_frames=7, grid_nx=6, grid_ny=4, vis_window=4, f0=1.0))
+    sc1 = sa.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K[0:1], 1, sc.row_ptr, sc.obs_frame, sc.obs_uv)
+    out = _phases(orc, gpu, sc1, 1.0, 1e-4)
+    _check(out, sc1.M, corr_tol=1e-7)
+
+
+# ------------------------------------------------------------------ end to end
+
+def _end_to_end(orc, gpu, sc, f0, allowed=None, max_factor=None, max_iterations=0):
+    so = _orc_scene(orc, sc)
+    rc_o, rep_o = orc.compute_inplace(f0, so, allowed, max_factor, max_iterations)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(allowed)
+    crit.MaxHessianFactor(max_factor)
+    sg = sc.copy()
+    ok = gpu.ComputeInplace(f0, sg, crit, max_iterations)
+    return rc_o, rep_o, so, ok, gpu.report, sg
+
+
+@pytest.mark.parametrize("name", ["tiny", "all_visible", "ragged_wave", "pixel_noise"])
+def test_compute_inplace_matches_oracle(orc, gpu, name):
+    spec = SCENES[name]
+    sc = sa.generate_scene(spec)
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, allowed=1e-12, max_factor=1e6)
+    assert ok == (rc_o == 0)
+    assert sa.status_string(rep.status) == orc.status_string(rep_o.status)
+    assert rep.seen == rep_o.seen
+    assert rep.err_initial == pytest.approx(rep_o.err_initial, rel=1e-12)
+    # identical accept / reject sequence (a fork on a near tie would show here)
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+    assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+    assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
+    assert rep.err_final < rep.err_initial
+
+
+def test_compute_inplace_iteration_cap_and_report(orc, gpu):
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, max_iterations=2)
+    assert not ok and rc_o == 1
+    assert sa.status_string(rep.status) == "max iterations" == orc.status_string(rep_o.status)
+    assert rep.iterations == 2 == rep_o.iterations and rep.attempts == rep_o.attempts
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6)
+    assert rep.ms_jacobian > 0 and rep.ms_schur > 0 and rep.ms_solve > 0
+    assert np.abs(sg.points - so.points).max() < 1e-6
+
+
+def test_abs_err_threshold_early_out(orc, gpu):
+    """err_initial < threshold -> true, 'abs err threshold', scene untouched up to the normalise/revert round trip
+    (bundle-adj-kanatani.cpp:749-753)."""
+    spec = sa.SceneSpec(n_frames=5, grid_nx=3, grid_ny=3, vis_window=3, noise_x3d_hi=0.0, noise_r_hi=0.0)
+    sc = sa.generate_scene(spec)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(1e-5)
+    sg = sc.copy()
+    assert gpu.ComputeInplace(spec.f0, sg, crit)
+    assert gpu.OptimizationStatusString() == "abs err threshold"
+    assert gpu.report.iterations == 0
+    assert np.abs(sg.points - sc.points).max() < 1e-12
+
+
+def test_normalisation_failure_returns_false(gpu):
+    """cam0 and cam1 at the same height along y: T01[y] ~ 0 -> ComputeInplace returns false, status string empty
+    (bundle-adj-kanatani.cpp:215-217, 681-682)."""
+    spec = sa.SceneSpec(n_frames=4, grid_nx=3, grid_ny=3, vis_window=0)
+    sc = sa.generate_scene(spec)
+    sc.cam_R[1] = sc.cam_R[0]
+    sc.cam_T[1] = sc.cam_T[0] + np.array([0.3, 0.0, 0.0])
+    before = sc.copy()
+    assert gpu.ComputeInplace(spec.f0, sc) is False
+    assert gpu.OptimizationStatusString() == ""
+    assert np.array_equal(sc.points, before.points)
+
+
+def test_argument_errors(gpu):
+    spec = SCENES["tiny"]
+    sc = sa.generate_scene(spec)
+    with pytest.raises(ValueError):       # CHECK(!IsClose(0, f0)) :420
+        gpu.ComputeInplace(0.0, sc.copy())
+    bad = sc.copy()
+    bad.obs_frame[1], bad.obs_frame[0] = bad.obs_frame[0], bad.obs_frame[1]
+    with pytest.raises(ValueError):
+        gpu.ComputeInplace(600.0, bad)
+    one = sa.Scene(sc.points, sc.cam_R[:1], sc.cam_T[:1], sc.K[:1], 0, sc.row_ptr, np.zeros_like(sc.obs_frame), sc.obs_uv)
+    with pytest.raises(ValueError):       # needs M >= 2
+        gpu.ReprojError(600.0, one)
+
+
+def test_reproj_error_api(orc, gpu):
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    e, seen = gpu.ReprojError(spec.f0, sc)
+    eo, so = orc.reproj_error(spec.f0, _orc_scene(orc, sc))
+    assert seen == so == sc.O
+    assert e == pytest.approx(eo, rel=1e-12)
+    assert gpu.ReprojErrorPixPerPoint(e, seen) == pytest.approx(spec.f0 * np.sqrt(eo / so), rel=1e-12)
+
+
+# ------------------------------------------------------------------ full-size properties (no oracle at this size)
+
+def test_c2_size_properties(gpu):
+    """BASELINE config 2 (200 cams / 20k pts / 400k obs): size-independent properties --
+    the error decreases monotonically over accepted iterations, the result is gauge-normalised before the revert,
+    and BA moves the noisy scene towards the ground truth."""
+    spec = sa.CONFIGS["C2_200cam_20kpt"]
+    sc, pts_gt, Rg, Tg = sa.generate_scene(spec, with_gt=True)
+    assert gpu.upload(spec.f0, sc)
+    e0, seen = gpu.phase_error()
+    assert seen == 400000
+    errs = [e0]
+    for _ in range(3):
+        ok = gpu.optimize(None, max_iterations=1)
+        assert not ok and gpu.OptimizationStatusString() == "max iterations"
+        errs.append(gpu.report.err_final)
+    assert all(b < a for a, b in zip(errs[:-1], errs[1:]))
+    assert errs[-1] < 1e-3 * errs[0]
+    nrm_scene = sc.copy()
+    gpu.download(nrm_scene, revert_normalization=False)
+    assert sa.check_world_is_normalized(nrm_scene)
+    out = sc.copy()
+    gpu.download(out, revert_normalization=True)
+    # the gauge leaves a similarity free, so compare through the reprojection error only
+    e_final, _ = gpu.ReprojError(spec.f0, out)
+    assert e_final == pytest.approx(errs[-1], rel=1e-6)
