@@ -174,7 +174,10 @@ class BundleAdjustmentKanatani:
         seen = C.c_int64(0)
         e = self._lib.srk_ba_reproj_error(C.c_void_p(self._h), C.c_double(f0), *scene.scene_args(), C.byref(seen))
         if math.isnan(e):
-            raise RuntimeError("srk_ba_reproj_error: " + self.last_error())
+            msg = self.last_error()
+            if "hip" in msg.lower():
+                raise RuntimeError("srk_ba_reproj_error: " + msg)
+            raise ValueError("srk_ba_reproj_error: " + msg)  # the reference CHECK-aborts on bad arguments (:420-421)
         self._f0 = float(f0)
         return float(e), int(seen.value)
 
