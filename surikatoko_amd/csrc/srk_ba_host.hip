@@ -450,7 +450,10 @@ extern "C" int srk_ba_download_scene(srk_ba* h, double* pts, double* cam_R, doub
 
 static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
 {
-    if (h->world <= 1 || !h->allreduce) return SRK_OK;
+    if (!h->allreduce) return SRK_OK;
+    // the hook reduces on its own (RCCL) stream: everything queued on ours must have landed first, and the hook
+    // returns only after the reduced values are visible
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     int rc = h->allreduce(h->allreduce_ctx, dev_ptr, count);
     if (rc != 0) {
         h->last_error = "allreduce hook failed";
@@ -648,7 +651,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     double hessian_factor = (double)0.0001f; // :723 (float literal)
     // seen_points_count over all shards (:483, :726)
     double seen_d = (double)d.O;
-    if (h->world > 1 && h->allreduce) {
+    if (h->allreduce) {
         HIPCHK(h, hipMemcpyAsync(h->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
         int rc = exchange(h, P<double>(h->err_out), 1);
         if (rc != SRK_OK) return fail_device(rc);
