@@ -532,7 +532,8 @@ static int phase_solve(srk_ba* h, bool profile)
         evs = h->chol_ev.data();
     }
     double* wy = P<double>(h->wy);
-    srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info), evs);
+    srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info), nullptr, nullptr,
+                   evs);
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
@@ -735,7 +736,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->schur_launches += 2;
             if (h->profile_syrk) {
                 int64_t nblk = d.ld / SRK_CHOL_NB;
-                for (int64_t kb = 0; kb + 1 < nblk; ++kb) {
+                for (int64_t kb = 0; kb < nblk; ++kb) {
                     float ms = 0;
                     if (hipEventElapsedTime(&ms, h->chol_ev[(size_t)(2 * kb)], h->chol_ev[(size_t)(2 * kb + 1)]) == hipSuccess)
                         rep->ms_solve_syrk += ms;
@@ -932,7 +933,8 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     HIPCHK(h, hipMemcpyAsync(dw.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemsetAsync(dinfo.p, 0, 4, s));
     HIPCHK(h, hipEventRecord(h->ev[14], s));
-    srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr);
+    srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr, nullptr,
+                   nullptr);
     HIPCHK(h, hipEventRecord(h->ev[15], s));
     HIPCHK(h, hipGetLastError());
     int info = 0;

@@ -29,7 +29,7 @@ struct SrkDims {
     int32_t comp;        // unity_t1_comp_ind (gauge), 1 by default
 };
 
-#define SRK_CHOL_NB 64
+#define SRK_CHOL_NB 256 // outer panel of the blocked Cholesky; ld is a multiple of it
 
 // ---- BA kernels (srk_ba_kernels.hip) ----
 void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double* T, const double* K, double f0,
@@ -56,7 +56,10 @@ void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_
 void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
 
 // ---- dense SPD solver (srk_chol.hip) ----
-// In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) followed by
-// forward/backward substitution of b into x.  info (device int) is set non-zero when a pivot is not positive/finite.
+// In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) with the forward
+// substitution folded in, then the backward substitution.  w: rhs (destroyed), y: scratch, x: solution.
+// info (device int) is set non-zero when a pivot is not positive/finite or the solution is not finite.
+// row_end / col_begin: optional host arrays describing the skyline of A (see srk_chol.hip); NULL = dense.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
+                    const int64_t* row_end, const int64_t* col_begin,
                     hipEvent_t* ev_pairs /* 2 * (ld / SRK_CHOL_NB) events or NULL */);
