@@ -8,7 +8,9 @@
 #include "srk_dev.hpp"
 #include "srk_geom.hpp"
 
+#include <algorithm>
 #include <chrono>
+#include <numeric>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +46,10 @@ struct srk_ba {
     DevBuf pts0, camR0, camT0; // copy of the uploaded (normalised) scene for srk_ba_reset_scene
     DevBuf row_ptr, obs_frame, obs_pt, obs_uv, col_ptr, fobs_pt, fobs_uv;
     DevBuf W, Vg, Ug, S, rhs, wy, dc, acc, dx, err_partial, err_out, info, scratch;
+    // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
+    std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
+    DevBuf grp_first, grp_count, gen_list;
+    int64_t n_groups = 0, n_generic = 0;
     int cur = 0; // index of the current scene buffers; 1-cur = trial
 
     // multi-GPU exchange
@@ -133,7 +139,8 @@ void srk_ba_destroy(srk_ba* h)
     DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->camR[0], &h->camR[1], &h->camT[0], &h->camT[1], &h->K, &h->cam[0],
                       &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
                       &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
-                      &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch };
+                      &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count,
+                      &h->gen_list };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
@@ -317,6 +324,60 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     std::vector<double> Kexp(9 * (int64_t)M);
     for (int32_t j = 0; j < M; ++j) std::memcpy(&Kexp[9 * (int64_t)j], shared_k ? K_in : K_in + 9 * (int64_t)j, 72);
 
+    // ---- internal landmark order: sorted by frame list, so that landmarks seeing exactly the same frames are
+    // contiguous (the grouped Schur kernel accumulates a run of them in registers and flushes once)
+    std::vector<int64_t> order((size_t)N);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    auto list_less = [&](int64_t x, int64_t y) {
+        int64_t ox = row_ptr[x], oy = row_ptr[y];
+        int64_t nx = row_ptr[x + 1] - ox, ny = row_ptr[y + 1] - oy;
+        if (nx == 0 || ny == 0) return nx < ny;
+        if (obs_frame[ox] != obs_frame[oy]) return obs_frame[ox] < obs_frame[oy];
+        if (nx != ny) return nx < ny;
+        for (int64_t k = 1; k < nx; ++k)
+            if (obs_frame[ox + k] != obs_frame[oy + k]) return obs_frame[ox + k] < obs_frame[oy + k];
+        return false;
+    };
+    std::stable_sort(order.begin(), order.end(), list_less);
+    auto same_list = [&](int64_t x, int64_t y) { return !list_less(x, y) && !list_less(y, x); };
+    h->perm = order;
+    h->row_ptr_user.assign(row_ptr, row_ptr + N + 1);
+    std::vector<int64_t> rp((size_t)N + 1, 0);
+    std::vector<int32_t> of((size_t)O);
+    std::vector<double> ouv((size_t)(2 * O)), ppts((size_t)(3 * N));
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t u = order[(size_t)i];
+        int64_t cnt = row_ptr[u + 1] - row_ptr[u];
+        rp[(size_t)i + 1] = rp[(size_t)i] + cnt;
+        std::memcpy(&of[(size_t)rp[(size_t)i]], obs_frame + row_ptr[u], (size_t)(4 * cnt));
+        std::memcpy(&ouv[(size_t)(2 * rp[(size_t)i])], obs_uv + 2 * row_ptr[u], (size_t)(16 * cnt));
+        std::memcpy(&ppts[(size_t)(3 * i)], &pts[(size_t)(3 * u)], 24);
+    }
+    h->row_ptr_int = rp;
+    pts.swap(ppts);
+    row_ptr = rp.data();
+    obs_frame = of.data();
+    obs_uv = ouv.data();
+    // runs of identical frame lists -> grouped kernel (<= SRK_GRP_MAXNF_HOST frames); the rest -> generic kernel
+    std::vector<int32_t> grp_first, grp_count, gen_list;
+    for (int64_t i = 0; i < N;) {
+        int64_t j = i + 1;
+        while (j < N && same_list(i, j)) ++j; // internal indices: row_ptr / obs_frame now are the permuted arrays
+        int64_t nf = rp[(size_t)i + 1] - rp[(size_t)i];
+        if (nf >= 1 && nf <= SRK_GRP_MAXNF_HOST) {
+            for (int64_t k = i; k < j; k += SRK_GRP_MAXPTS_HOST) {
+                grp_first.push_back((int32_t)k);
+                grp_count.push_back((int32_t)std::min<int64_t>(SRK_GRP_MAXPTS_HOST, j - k));
+            }
+        } else {
+            for (int64_t k = i; k < j; ++k)
+                if (nf > 0) gen_list.push_back((int32_t)k);
+        }
+        i = j;
+    }
+    h->n_groups = (int64_t)grp_first.size();
+    h->n_generic = (int64_t)gen_list.size();
+
     SrkDims d{};
     d.N = N;
     d.M = M;
@@ -330,7 +391,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     h->d = d;
     h->f0 = f0;
 
-    // observation side tables: obs -> point, and the frame-major copy (ordered by frame, then pnt_ind)
+    // observation side tables: obs -> point, and the frame-major copy (ordered by frame, then landmark)
     std::vector<int32_t> obs_pt((size_t)O);
     std::vector<int64_t> col_ptr((size_t)M + 1, 0);
     for (int64_t i = 0; i < N; ++i)
@@ -389,6 +450,9 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->err_partial, 8 * 1024);
     ALLOC(h->err_out, 64);
     ALLOC(h->info, 64);
+    ALLOC(h->grp_first, 4 * grp_first.size());
+    ALLOC(h->grp_count, 4 * grp_count.size());
+    ALLOC(h->gen_list, 4 * gen_list.size());
 #undef ALLOC
     hipStream_t s = h->stream;
 #define H2D(buf, src, bytes)                                                                               \
@@ -409,6 +473,9 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->col_ptr, col_ptr.data(), 8 * ((int64_t)M + 1));
     H2D(h->fobs_pt, fobs_pt.data(), 4 * O);
     H2D(h->fobs_uv, fobs_uv.data(), 16 * O);
+    H2D(h->grp_first, grp_first.data(), 4 * grp_first.size());
+    H2D(h->grp_count, grp_count.data(), 4 * grp_count.size());
+    H2D(h->gen_list, gen_list.data(), 4 * gen_list.size());
 #undef H2D
     HIPCHK(h, hipMemsetAsync(h->dc.p, 0, 8 * d.ld, s));
     HIPCHK(h, hipMemsetAsync(h->dx.p, 0, 24 * N > 0 ? 24 * N : 8, s));
@@ -438,10 +505,12 @@ extern "C" int srk_ba_download_scene(srk_ba* h, double* pts, double* cam_R, doub
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     int c = h->cur;
-    if (h->d.N > 0) HIPCHK(h, hipMemcpyAsync(pts, h->pts[c].p, 24 * h->d.N, hipMemcpyDeviceToHost, s));
+    std::vector<double> tmp((size_t)(3 * h->d.N));
+    if (h->d.N > 0) HIPCHK(h, hipMemcpyAsync(tmp.data(), h->pts[c].p, 24 * h->d.N, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(cam_R, h->camR[c].p, 72 * (int64_t)h->d.M, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(cam_T, h->camT[c].p, 24 * (int64_t)h->d.M, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    for (int64_t i = 0; i < h->d.N; ++i) std::memcpy(pts + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
     if (revert && h->normalized_on_upload) srk_ba_revert_normalization(h->d.N, pts, h->d.M, cam_R, cam_T, &h->nrm); // :706
     return SRK_OK;
 }
@@ -502,8 +571,11 @@ static int phase_schur(srk_ba* h, double c)
     hipStream_t s = h->stream;
     HIPCHK(h, hipMemsetAsync(h->S.p, 0, 8 * d.ld * d.ld, s));
     HIPCHK(h, hipMemsetAsync(h->rhs.p, 0, 8 * d.ld, s));
+    srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W),
+                             P<double>(h->Vg), P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->grp_first),
+                             P<int32_t>(h->grp_count), h->n_groups);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
-                     P<double>(h->S), P<double>(h->rhs));
+                     P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());
     // landmark shards: sum the partial Schur sums and right-hand sides, then add the (global) frame blocks
     int rc = exchange(h, P<double>(h->S), d.ld * d.ld);
@@ -855,11 +927,11 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
         if (which == SRK_BUF_POINT_BLOCKS) {
             static const int map[9] = { 0, 1, 2, 1, 3, 4, 2, 4, 5 };
             for (int64_t i = 0; i < d.N; ++i)
-                for (int e = 0; e < 9; ++e) dst[9 * i + e] = vg[(size_t)(map[e] * d.Ns + i)];
+                for (int e = 0; e < 9; ++e) dst[9 * h->perm[(size_t)i] + e] = vg[(size_t)(map[e] * d.Ns + i)];
             return SRK_OK;
         }
         for (int64_t i = 0; i < d.N; ++i)
-            for (int e = 0; e < 3; ++e) dst[3 * i + e] = vg[(size_t)((6 + e) * d.Ns + i)];
+            for (int e = 0; e < 3; ++e) dst[3 * h->perm[(size_t)i] + e] = vg[(size_t)((6 + e) * d.Ns + i)];
         std::vector<double> ug((size_t)(SRK_UG * (int64_t)d.M));
         if ((rc = d2h(ug.data(), h->Ug.p, ug.size() * 8)) != SRK_OK) return rc;
         for (int32_t j = 0; j < d.M; ++j)
@@ -880,8 +952,12 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     case SRK_BUF_POINT_FRAME: {
         std::vector<double> w((size_t)(30 * d.Os));
         if ((rc = d2h(w.data(), h->W.p, w.size() * 8)) != SRK_OK) return rc;
-        for (int64_t o = 0; o < d.O; ++o)
-            for (int k = 0; k < 30; ++k) dst[30 * o + k] = w[(size_t)(k * d.Os + o)];
+        for (int64_t i = 0; i < d.N; ++i) {
+            int64_t oi = h->row_ptr_int[(size_t)i], ou = h->row_ptr_user[(size_t)h->perm[(size_t)i]];
+            int64_t cnt = h->row_ptr_int[(size_t)i + 1] - oi;
+            for (int64_t a = 0; a < cnt; ++a)
+                for (int k = 0; k < 30; ++k) dst[30 * (ou + a) + k] = w[(size_t)(k * d.Os + oi + a)];
+        }
         return SRK_OK;
     }
     case SRK_BUF_RCS: {
@@ -898,10 +974,17 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     }
     case SRK_BUF_RCS_RHS: return d2h(dst, h->rhs.p, (size_t)(80 * (int64_t)d.M));
     case SRK_BUF_CORRECTIONS: {
-        if ((rc = d2h(dst, h->dx.p, (size_t)(24 * d.N))) != SRK_OK) return rc;
+        std::vector<double> tmp((size_t)(3 * d.N));
+        if ((rc = d2h(tmp.data(), h->dx.p, (size_t)(24 * d.N))) != SRK_OK) return rc;
+        for (int64_t i = 0; i < d.N; ++i) std::memcpy(dst + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
         return d2h(dst + 3 * d.N, h->dc.p, (size_t)(80 * (int64_t)d.M));
     }
-    case SRK_BUF_POINTS: return d2h(dst, h->pts[h->cur].p, (size_t)(24 * d.N));
+    case SRK_BUF_POINTS: {
+        std::vector<double> tmp((size_t)(3 * d.N));
+        if ((rc = d2h(tmp.data(), h->pts[h->cur].p, (size_t)(24 * d.N))) != SRK_OK) return rc;
+        for (int64_t i = 0; i < d.N; ++i) std::memcpy(dst + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
+        return SRK_OK;
+    }
     case SRK_BUF_CAM_R: return d2h(dst, h->camR[h->cur].p, (size_t)(72 * (int64_t)d.M));
     case SRK_BUF_CAM_T: return d2h(dst, h->camT[h->cur].p, (size_t)(24 * (int64_t)d.M));
     default: return SRK_E_ARGS;

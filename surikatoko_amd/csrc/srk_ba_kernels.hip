@@ -324,12 +324,14 @@ __device__ __forceinline__ bool point_block_inverse(const double* __restrict__ V
 __global__ __launch_bounds__(256) void k_schur(SrkDims d, double c, const int64_t* __restrict__ row_ptr,
                                                const int32_t* __restrict__ obs_frame, const double* __restrict__ W,
                                                const double* __restrict__ Vg, double* __restrict__ S,
-                                               double* __restrict__ rhs)
+                                               double* __restrict__ rhs, const int32_t* __restrict__ pt_list,
+                                               int64_t n_list)
 {
     __shared__ double sWa[SRK_SCH][30];
     __shared__ double sYb[SRK_SCH][30];
     __shared__ int32_t sFa[SRK_SCH], sFb[SRK_SCH];
-    for (int64_t pt = blockIdx.x; pt < d.N; pt += gridDim.x) {
+    for (int64_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        int64_t pt = pt_list ? pt_list[li] : li;
         double Einv[9], g[3];
         bool ok = point_block_inverse(Vg, d.Ns, pt, c, Einv, g); // block-uniform
         if (!ok) continue;                                        // :1877-1881 skip the landmark
@@ -391,11 +393,155 @@ __global__ __launch_bounds__(256) void k_schur(SrkDims d, double c, const int64_
 }
 
 void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_frame,
-                      const double* W, const double* Vg, double* S, double* rhs)
+                      const double* W, const double* Vg, double* S, double* rhs, const int32_t* pt_list,
+                      int64_t n_list)
 {
-    if (d.N == 0) return;
-    int64_t blocks = d.N < 65536 ? d.N : 65536;
-    hipLaunchKernelGGL(k_schur, dim3((unsigned)blocks), dim3(256), 0, s, d, c, row_ptr, obs_frame, W, Vg, S, rhs);
+    if (n_list <= 0) return;
+    int64_t blocks = n_list < 65536 ? n_list : 65536;
+    hipLaunchKernelGGL(k_schur, dim3((unsigned)blocks), dim3(256), 0, s, d, c, row_ptr, obs_frame, W, Vg, S, rhs,
+                       pt_list, n_list);
+}
+
+// ------------------------------------------------------------------ K3g: Schur accumulation, grouped landmarks
+// Landmarks are stored sorted by their frame list, so landmarks that see exactly the same frames are contiguous.
+// One workgroup takes a run of such landmarks (<= SRK_GRP_MAXPTS) and keeps the whole lower block triangle of their
+// common nf x nf frame-pair blocks in REGISTERS (2x10 strips, <= SRK_GRP_SLOTS per thread); every landmark's 3x3
+// elimination block is inverted once, W_i and Y_i = E_i^-1 W_i are staged in LDS, and the sums leave the chip once
+// per run as fp64 atomics -- ~100x fewer atomic bytes than one flush per landmark.
+#define SRK_GRP_THREADS 512
+#define SRK_GRP_SLOTS 3
+#define SRK_GRP_MAXNF 24   // nf (nf + 1) / 2 * 5 strips <= SRK_GRP_THREADS * SRK_GRP_SLOTS
+#define SRK_GRP_PB 4       // landmarks staged per barrier pair
+
+__global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
+    SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_frame,
+    const double* __restrict__ W, const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
+    const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count)
+{
+    __shared__ __attribute__((aligned(16))) double sW[SRK_GRP_PB][SRK_GRP_MAXNF * 30];
+    __shared__ __attribute__((aligned(16))) double sY[SRK_GRP_PB][SRK_GRP_MAXNF * 30];
+    __shared__ double sE[SRK_GRP_PB][12];
+    __shared__ int32_t sF[SRK_GRP_MAXNF];
+    const int tid = threadIdx.x;
+    const int64_t p0 = grp_first[blockIdx.x];
+    const int np = grp_count[blockIdx.x];
+    const int64_t o0 = row_ptr[p0];
+    const int nf = (int)(row_ptr[p0 + 1] - o0);
+    if (tid < nf) sF[tid] = obs_frame[o0 + tid];
+    // strip u -> (block pair (a, b), b <= a ; rows r0, r0 + 1)
+    const int n_strips = nf * (nf + 1) / 2 * 5;
+    int offW[SRK_GRP_SLOTS], offY[SRK_GRP_SLOTS], sa[SRK_GRP_SLOTS], sb[SRK_GRP_SLOTS], sr[SRK_GRP_SLOTS];
+    bool act[SRK_GRP_SLOTS];
+#pragma unroll
+    for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+        int u = tid + s * SRK_GRP_THREADS;
+        act[s] = u < n_strips;
+        int pi = act[s] ? u / 5 : 0;
+        int ru = act[s] ? u - pi * 5 : 0;
+        int a = (int)((sqrtf(8.0f * (float)pi + 1.0f) - 1.0f) * 0.5f);
+        while ((a + 1) * (a + 2) / 2 <= pi) ++a;
+        while (a * (a + 1) / 2 > pi) --a;
+        int b = pi - a * (a + 1) / 2;
+        sa[s] = a; sb[s] = b; sr[s] = 2 * ru;
+        offW[s] = a * 30 + 2 * ru;
+        offY[s] = b * 30;
+    }
+    double acc[SRK_GRP_SLOTS][2][10];
+#pragma unroll
+    for (int s = 0; s < SRK_GRP_SLOTS; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cc = 0; cc < 10; ++cc) acc[s][i][cc] = 0;
+    double racc = 0; // rhs accumulator: thread t < 10 nf owns entry (a = t / 10, r = t % 10)
+    const int n30 = nf * 30;
+    for (int pb = 0; pb < np; pb += SRK_GRP_PB) {
+        int nb = np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB;
+        __syncthreads();
+        if (tid < nb) { // 3x3 damped block inverse; a singular block contributes nothing (:1877-1881)
+            double Einv[9], g[3];
+            bool ok = point_block_inverse(Vg, d.Ns, p0 + pb + tid, c, Einv, g);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
+        }
+        // W of the staged landmarks: the run is contiguous in the observation arrays
+        for (int t = tid; t < nb * n30; t += SRK_GRP_THREADS) {
+            int pl = t / n30, e = t - pl * n30;
+            int k = e / nf, a = e - k * nf; // lanes walk `a` (contiguous in memory) first
+            sW[pl][a * 30 + k] = W[(int64_t)k * d.Os + o0 + (int64_t)(pb + pl) * nf + a];
+        }
+        __syncthreads();
+        for (int t = tid; t < nb * nf * 10; t += SRK_GRP_THREADS) {
+            int pl = t / (nf * 10), e = t - pl * nf * 10;
+            int a = e / 10, fv = e - a * 10;
+            const double* Ei = sE[pl];
+            double w0 = sW[pl][a * 30 + fv], w1 = sW[pl][a * 30 + 10 + fv], w2 = sW[pl][a * 30 + 20 + fv];
+            sY[pl][a * 30 + fv] = Ei[0] * w0 + Ei[1] * w1 + Ei[2] * w2;
+            sY[pl][a * 30 + 10 + fv] = Ei[3] * w0 + Ei[4] * w1 + Ei[5] * w2;
+            sY[pl][a * 30 + 20 + fv] = Ei[6] * w0 + Ei[7] * w1 + Ei[8] * w2;
+        }
+        __syncthreads();
+        for (int pl = 0; pl < nb; ++pl) {
+            const double* w = sW[pl];
+            const double* yv = sY[pl];
+#pragma unroll
+            for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+                if (!act[s]) continue;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    double2 wv = *reinterpret_cast<const double2*>(w + offW[s] + 10 * m);
+                    const double2* yp = reinterpret_cast<const double2*>(yv + offY[s] + 10 * m);
+#pragma unroll
+                    for (int h = 0; h < 5; ++h) {
+                        double2 y2 = yp[h];
+                        acc[s][0][2 * h] = fma(wv.x, y2.x, acc[s][0][2 * h]);
+                        acc[s][0][2 * h + 1] = fma(wv.x, y2.y, acc[s][0][2 * h + 1]);
+                        acc[s][1][2 * h] = fma(wv.y, y2.x, acc[s][1][2 * h]);
+                        acc[s][1][2 * h + 1] = fma(wv.y, y2.y, acc[s][1][2 * h + 1]);
+                    }
+                }
+            }
+            if (tid < nf * 10) {
+                int a = tid / 10, r = tid - a * 10;
+                const double* Eg = sE[pl] + 9;
+                racc += w[a * 30 + r] * Eg[0] + w[a * 30 + 10 + r] * Eg[1] + w[a * 30 + 20 + r] * Eg[2];
+            }
+        }
+    }
+    // flush: S -= sum F^T E^-1 F (lower block triangle), rhs += sum F^T E^-1 g, gauge rows/columns dropped
+#pragma unroll
+    for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+        if (!act[s]) continue;
+        int64_t rowb = 10 * (int64_t)sF[sa[s]] + sr[s], colb = 10 * (int64_t)sF[sb[s]];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int64_t row = rowb + i;
+            if (srk_is_fixed_var(row, d.comp)) continue;
+#pragma unroll
+            for (int cc = 0; cc < 10; ++cc) {
+                int64_t col = colb + cc;
+                if (srk_is_fixed_var(col, d.comp)) continue;
+                atomicAdd(&S[row * d.ld + col], -acc[s][i][cc]);
+            }
+        }
+    }
+    if (tid < nf * 10) {
+        int a = tid / 10, r = tid - a * 10;
+        int64_t row = 10 * (int64_t)sF[a] + r;
+        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], racc);
+    }
+}
+
+void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr,
+                              const int32_t* obs_frame, const double* W, const double* Vg, double* S, double* rhs,
+                              const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups)
+{
+    if (n_groups <= 0) return;
+    hipLaunchKernelGGL(k_schur_grouped, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr,
+                       obs_frame, W, Vg, S, rhs, grp_first, grp_count);
 }
 
 // G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark

@@ -41,7 +41,13 @@ void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_ob
                            const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
                            double* Ug);
 void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_frame,
-                      const double* W, const double* Vg, double* S, double* rhs);
+                      const double* W, const double* Vg, double* S, double* rhs, const int32_t* pt_list,
+                      int64_t n_list);
+#define SRK_GRP_MAXNF_HOST 24   // must match SRK_GRP_MAXNF in srk_ba_kernels.hip
+#define SRK_GRP_MAXPTS_HOST 128 // landmarks per workgroup run
+void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr,
+                              const int32_t* obs_frame, const double* W, const double* Vg, double* S, double* rhs,
+                              const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs);
 void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,
                         const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
