@@ -163,6 +163,14 @@ enum srk_buffer {
 int64_t srk_ba_buffer_size(srk_ba*, int which);                 /* doubles; negative on error */
 int srk_ba_download(srk_ba*, int which, double* dst, int64_t count);
 
+/* The reduced camera system is non-zero only where two frames share a landmark; the solver skips everything
+ * outside that skyline (exact: Cholesky fill stays inside it).  With landmark shards every rank must be given the
+ * GLOBAL covisibility after upload: min_cv[j] = smallest frame index sharing a landmark with frame j. */
+int srk_ba_set_covisibility(srk_ba*, const int32_t* min_cv /* [M], NULL = dense */);
+int srk_ba_set_rcs_mode(srk_ba*, int use_envelope /* 0 = dense lower triangle, 1 = skyline (default) */);
+double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
+double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current skyline) */
+
 /* bench knob: record event pairs around every MFMA trailing-update launch (fills report.ms_solve_syrk) */
 int srk_ba_set_profile(srk_ba*, int profile_syrk);
 

@@ -56,6 +56,7 @@ EXPORTS = [
     "srk_ba_upload_scene", "srk_ba_optimize", "srk_ba_download_scene", "srk_ba_reset_scene", "srk_ba_phase_error",
     "srk_ba_phase_derivatives", "srk_ba_phase_schur", "srk_ba_phase_solve", "srk_ba_phase_backsub",
     "srk_ba_phase_accept", "srk_ba_buffer_size", "srk_ba_download", "srk_ba_set_profile", "srk_ba_dense_spd_solve",
+    "srk_ba_set_covisibility", "srk_ba_set_rcs_mode", "srk_ba_rcs_fill", "srk_ba_solve_mfma_flops",
     "srk_scene_num_observations", "srk_scene_generate", "srk_circle_camera_shots",
 ]
 
@@ -82,6 +83,10 @@ def lib():
     L.srk_ba_buffer_size.restype = C.c_int64
     L.srk_ba_buffer_size.argtypes = [C.c_void_p, C.c_int]
     L.srk_scene_num_observations.restype = C.c_int64
+    L.srk_ba_rcs_fill.restype = C.c_double
+    L.srk_ba_rcs_fill.argtypes = [C.c_void_p]
+    L.srk_ba_solve_mfma_flops.restype = C.c_double
+    L.srk_ba_solve_mfma_flops.argtypes = [C.c_void_p]
     L.srk_ba_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.srk_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]
     L.srk_ba_revert_normalization.restype = None

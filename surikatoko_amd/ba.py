@@ -67,6 +67,18 @@ class Scene:
                 C.c_int(self.shared_k), _p(self.row_ptr), _p(self.obs_frame), _p(self.obs_uv))
 
 
+def covisibility(scene):
+    """min_cv[j] = smallest frame index that shares a landmark with frame j (the skyline of the reduced camera
+    system); computed on the WHOLE scene before sharding."""
+    M = scene.M
+    first = scene.obs_frame[scene.row_ptr[:-1][np.diff(scene.row_ptr) > 0]]
+    counts = np.diff(scene.row_ptr)
+    first_per_obs = np.repeat(first, counts[counts > 0])
+    min_cv = np.arange(M, dtype=np.int64)
+    np.minimum.at(min_cv, scene.obs_frame, first_per_obs)
+    return min_cv.astype(np.int32)
+
+
 def shard_bounds(row_ptr, rank, world):
     """Contiguous pnt_ind range [lo, hi) of `rank`: cut points chosen so every rank gets ~O/world observations."""
     row_ptr = np.asarray(row_ptr)
@@ -230,6 +242,23 @@ class BundleAdjustmentKanatani:
 
     def set_profile(self, on=True):
         self._raise(self._lib.srk_ba_set_profile(C.c_void_p(self._h), C.c_int(int(on))))
+
+    def set_covisibility(self, min_cv):
+        """Global covisibility for sharded runs (see covisibility()); None = dense."""
+        if min_cv is None:
+            self._raise(self._lib.srk_ba_set_covisibility(C.c_void_p(self._h), None))
+        else:
+            a = np.ascontiguousarray(min_cv, dtype=np.int32)
+            self._raise(self._lib.srk_ba_set_covisibility(C.c_void_p(self._h), _p(a)))
+
+    def set_rcs_mode(self, use_envelope=True):
+        self._raise(self._lib.srk_ba_set_rcs_mode(C.c_void_p(self._h), C.c_int(int(use_envelope))))
+
+    def solve_mfma_flops(self):
+        return float(self._lib.srk_ba_solve_mfma_flops(C.c_void_p(self._h)))
+
+    def rcs_fill(self):
+        return float(self._lib.srk_ba_rcs_fill(C.c_void_p(self._h)))
 
     def set_stream(self, hip_stream_handle):
         self._raise(self._lib.srk_ba_set_stream(C.c_void_p(self._h), C.c_void_p(hip_stream_handle)))

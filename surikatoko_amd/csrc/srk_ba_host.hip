@@ -50,6 +50,12 @@ struct srk_ba {
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
     DevBuf grp_first, grp_count, gen_list;
     int64_t n_groups = 0, n_generic = 0;
+    // skyline of the reduced camera system (see k_env_zero): host + device copies
+    std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
+    std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
+    DevBuf env_col, env_off, packed;
+    int64_t env_packed = 0;
+    bool use_envelope = true;
     int cur = 0; // index of the current scene buffers; 1-cur = trial
 
     // multi-GPU exchange
@@ -140,7 +146,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
                       &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
                       &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count,
-                      &h->gen_list };
+                      &h->gen_list, &h->env_col, &h->env_off, &h->packed };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
@@ -293,6 +299,48 @@ static int compute_cam_packs(srk_ba* h, int which)
     srk_launch_cam_pack(h->stream, h->d.M, P<double>(h->camR[which]), P<double>(h->camT[which]), P<double>(h->K),
                         h->f0, P<double>(h->cam[which]));
     HIPCHK(h, hipGetLastError());
+    return SRK_OK;
+}
+
+// Skyline of the RCS from the covisibility (min_cv[j] = smallest frame index sharing a landmark with frame j).
+// All quantities are aligned to the solver's blocking: env_col multiples of 256, row_end multiples of 128.
+static int build_envelope(srk_ba* h)
+{
+    const SrkDims& d = h->d;
+    const int64_t nt = d.ld / 128, nk = d.ld / SRK_CHOL_NB, n64 = d.ld / 64;
+    h->env_col_h.assign((size_t)nt, 0);
+    for (int64_t t = 0; t < nt; ++t) {
+        int64_t r0 = 128 * t, r1 = 128 * t + 127;
+        int64_t fc = r0; // padding rows and the diagonal itself
+        if (h->use_envelope) {
+            for (int64_t j = r0 / 10; j <= r1 / 10 && j < d.M; ++j) fc = std::min<int64_t>(fc, 10 * (int64_t)h->min_cv[(size_t)j]);
+        } else {
+            fc = 0;
+        }
+        h->env_col_h[(size_t)t] = (fc / SRK_CHOL_NB) * SRK_CHOL_NB;
+    }
+    h->row_end_h.assign((size_t)nk, 0);
+    for (int64_t K = 0; K < nk; ++K) {
+        int64_t last = -1;
+        for (int64_t t = nt - 1; t >= 0; --t)
+            if (h->env_col_h[(size_t)t] <= SRK_CHOL_NB * K) { last = t; break; }
+        int64_t re = 128 * (last + 1);
+        re = std::max<int64_t>(re, SRK_CHOL_NB * (K + 1));
+        h->row_end_h[(size_t)K] = std::min<int64_t>(re, d.ld);
+    }
+    h->col_begin_h.assign((size_t)n64, 0);
+    for (int64_t q = 0; q < n64; ++q) h->col_begin_h[(size_t)q] = h->env_col_h[(size_t)(q / 2)];
+    h->env_off_h.assign((size_t)nt + 1, 0);
+    for (int64_t t = 0; t < nt; ++t)
+        h->env_off_h[(size_t)t + 1] = h->env_off_h[(size_t)t] + 128 * (128 * (t + 1) - h->env_col_h[(size_t)t]);
+    h->env_packed = h->env_off_h[(size_t)nt];
+    int rc;
+    if ((rc = dev_alloc(h, h->env_col, (size_t)(8 * nt))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, h->env_off, (size_t)(8 * (nt + 1)))) != SRK_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->env_col.p, h->env_col_h.data(), (size_t)(8 * nt), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->env_off.p, h->env_off_h.data(), (size_t)(8 * (nt + 1)), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->S.p, 0, (size_t)(8 * d.ld * d.ld), h->stream)); // everything outside the skyline stays 0
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return SRK_OK;
 }
 
@@ -483,6 +531,20 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     rc = compute_cam_packs(h, 0);
     if (rc != SRK_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(s)); // host staging vectors go out of scope
+    // covisibility of THIS shard; with several ranks the caller must supply the global one
+    // (srk_ba_set_covisibility) -- until then the skyline is the full lower triangle
+    h->min_cv.assign((size_t)M, 0);
+    if (!h->allreduce) {
+        for (int32_t j = 0; j < M; ++j) h->min_cv[(size_t)j] = j;
+        for (int64_t i = 0; i < N; ++i) {
+            if (row_ptr[i + 1] == row_ptr[i]) continue;
+            int32_t first = obs_frame[row_ptr[i]];
+            for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o)
+                h->min_cv[(size_t)obs_frame[o]] = std::min(h->min_cv[(size_t)obs_frame[o]], first);
+        }
+    }
+    rc = build_envelope(h);
+    if (rc != SRK_OK) return rc;
     h->have_scene = true;
     return SRK_OK;
 }
@@ -569,7 +631,7 @@ static int phase_schur(srk_ba* h, double c)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
-    HIPCHK(h, hipMemsetAsync(h->S.p, 0, 8 * d.ld * d.ld, s));
+    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->S));
     HIPCHK(h, hipMemsetAsync(h->rhs.p, 0, 8 * d.ld, s));
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W),
                              P<double>(h->Vg), P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->grp_first),
@@ -578,8 +640,14 @@ static int phase_schur(srk_ba* h, double c)
                      P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());
     // landmark shards: sum the partial Schur sums and right-hand sides, then add the (global) frame blocks
-    int rc = exchange(h, P<double>(h->S), d.ld * d.ld);
-    if (rc != SRK_OK) return rc;
+    int rc = SRK_OK;
+    if (h->allreduce) { // only the skyline travels: pack -> all-reduce -> unpack
+        if ((rc = dev_alloc(h, h->packed, (size_t)(8 * h->env_packed))) != SRK_OK) return rc;
+        srk_launch_env_pack(s, d.ld, P<int64_t>(h->env_col), P<int64_t>(h->env_off), P<double>(h->S), P<double>(h->packed), 0);
+        rc = exchange(h, P<double>(h->packed), h->env_packed);
+        if (rc != SRK_OK) return rc;
+        srk_launch_env_pack(s, d.ld, P<int64_t>(h->env_col), P<int64_t>(h->env_off), P<double>(h->S), P<double>(h->packed), 1);
+    }
     rc = exchange(h, P<double>(h->rhs), d.ld);
     if (rc != SRK_OK) return rc;
     srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->S), P<double>(h->rhs));
@@ -604,8 +672,8 @@ static int phase_solve(srk_ba* h, bool profile)
         evs = h->chol_ev.data();
     }
     double* wy = P<double>(h->wy);
-    srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info), nullptr, nullptr,
-                   evs);
+    srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info),
+                   h->row_end_h.data(), h->col_begin_h.data(), evs);
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
@@ -1032,6 +1100,53 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     std::memcpy(x, bp.data(), (size_t)(8 * n));
     dev_free(dA); dev_free(dw); dev_free(dy); dev_free(dx); dev_free(dinfo);
     return info ? 1 : 0;
+}
+
+// global covisibility for sharded runs: min_cv[j] = smallest frame index that shares a landmark with frame j,
+// taken over ALL ranks' landmarks.  Call after srk_ba_upload_scene.  NULL = dense (full lower triangle).
+int srk_ba_set_covisibility(srk_ba* h, const int32_t* min_cv)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (min_cv) {
+        for (int32_t j = 0; j < h->d.M; ++j) {
+            if (min_cv[j] < 0 || min_cv[j] > j) { h->last_error = "min_cv[j] must be in [0, j]"; return SRK_E_ARGS; }
+            h->min_cv[(size_t)j] = min_cv[j];
+        }
+    } else {
+        std::fill(h->min_cv.begin(), h->min_cv.end(), 0);
+    }
+    return build_envelope(h);
+}
+
+// 0 = treat the reduced camera system as dense (full lower triangle), 1 = exploit its skyline (default)
+int srk_ba_set_rcs_mode(srk_ba* h, int use_envelope)
+{
+    if (!h) return SRK_E_ARGS;
+    h->use_envelope = use_envelope != 0;
+    if (h->have_scene) return build_envelope(h);
+    return SRK_OK;
+}
+
+// fraction of the lower triangle inside the skyline (1.0 = dense)
+double srk_ba_rcs_fill(srk_ba* h)
+{
+    if (!h || !h->have_scene) return -1.0;
+    double full = 0.5 * (double)h->d.ld * (double)h->d.ld;
+    return (double)h->env_packed / full;
+}
+
+// flops executed by the MFMA trailing updates of one solve with the current skyline (2 flops per FMA)
+double srk_ba_solve_mfma_flops(srk_ba* h)
+{
+    if (!h || !h->have_scene) return -1.0;
+    double f = 0;
+    const int64_t nk = h->d.ld / SRK_CHOL_NB;
+    for (int64_t K = 0; K < nk; ++K) {
+        int64_t T = (h->row_end_h[(size_t)K] - SRK_CHOL_NB * (K + 1)) / 128;
+        if (T > 0) f += (double)(T * (T + 1) / 2) * 128.0 * 128.0 * (double)SRK_CHOL_NB * 2.0;
+    }
+    return f;
 }
 
 // knob for bench.py: event pairs around every MFMA trailing-update launch (report.ms_solve_syrk)

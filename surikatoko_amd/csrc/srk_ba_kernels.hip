@@ -791,3 +791,42 @@ void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const 
                        partial);
     hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, err_out);
 }
+
+// ------------------------------------------------------------------ skyline (envelope) helpers for the RCS
+// The reduced camera system is non-zero only where two frames share a landmark.  env_col[t] is the first column
+// (multiple of 256) that can be non-zero in the 128-row tile row t; Cholesky fill stays inside that skyline.
+// zero / pack / unpack touch only rows' segments [env_col[t], 128 (t + 1)) -- the lower triangle inside the skyline.
+__global__ __launch_bounds__(256) void k_env_zero(int64_t ld, const int64_t* __restrict__ env_col, double* __restrict__ S)
+{
+    int64_t t = blockIdx.y;
+    int64_t c0 = env_col[t], c1 = 128 * (t + 1);
+    int64_t row = 128 * t + blockIdx.x;
+    double* p = S + row * ld;
+    for (int64_t c = c0 + 2 * threadIdx.x; c < c1; c += 512) *reinterpret_cast<double2*>(p + c) = make_double2(0.0, 0.0);
+}
+void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S)
+{
+    hipLaunchKernelGGL(k_env_zero, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, S);
+}
+
+// pack: out[env_off[t] + r * w + (c - c0)] = S[row][c], w = c1 - c0 ; dir = 0 pack, 1 unpack
+__global__ __launch_bounds__(256) void k_env_pack(int64_t ld, const int64_t* __restrict__ env_col,
+                                                  const int64_t* __restrict__ env_off, double* __restrict__ S,
+                                                  double* __restrict__ packed, int dir)
+{
+    int64_t t = blockIdx.y;
+    int64_t c0 = env_col[t], c1 = 128 * (t + 1), w = c1 - c0;
+    int64_t r = blockIdx.x;
+    double* ps = S + (128 * t + r) * ld + c0;
+    double* pp = packed + env_off[t] + r * w;
+    for (int64_t c = threadIdx.x; c < w; c += 256) {
+        if (dir == 0) pp[c] = ps[c];
+        else ps[c] = pp[c];
+    }
+}
+void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
+                         double* packed, int dir)
+{
+    hipLaunchKernelGGL(k_env_pack, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, env_off, S, packed,
+                       dir);
+}

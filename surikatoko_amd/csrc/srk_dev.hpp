@@ -61,6 +61,10 @@ int32_t srk_error_partials(const SrkDims& d);
 void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full);
 void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
 
+void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S);
+void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
+                         double* packed, int dir);
+
 // ---- dense SPD solver (srk_chol.hip) ----
 // In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) with the forward
 // substitution folded in, then the backward substitution.  w: rhs (destroyed), y: scratch, x: solution.
