@@ -48,8 +48,9 @@ struct srk_ba {
     DevBuf W, Vg, Ug, S, rhs, wy, dc, acc, dx, err_partial, err_out, info, scratch;
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
-    DevBuf grp_first, grp_count, gen_list;
+    DevBuf grp_first, grp_count, gen_list, wg_jmin;
     int64_t n_groups = 0, n_generic = 0;
+    bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
     std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
@@ -146,7 +147,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
                       &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
                       &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count,
-                      &h->gen_list, &h->env_col, &h->env_off, &h->packed };
+                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
@@ -425,6 +426,18 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     }
     h->n_groups = (int64_t)grp_first.size();
     h->n_generic = (int64_t)gen_list.size();
+    // frame range of every SRK_JF_OBS_HOST-observation workgroup of the fused Jacobian kernel
+    std::vector<int32_t> wg_jmin;
+    h->jac_fused = true;
+    for (int64_t o0 = 0; o0 < O; o0 += SRK_JF_OBS_HOST) {
+        int32_t lo = obs_frame[o0], hi = obs_frame[o0];
+        for (int64_t o = o0; o < std::min<int64_t>(O, o0 + SRK_JF_OBS_HOST); ++o) {
+            lo = std::min(lo, obs_frame[o]);
+            hi = std::max(hi, obs_frame[o]);
+        }
+        if (hi - lo >= SRK_JF_SLOTS_HOST) h->jac_fused = false;
+        wg_jmin.push_back(lo);
+    }
 
     SrkDims d{};
     d.N = N;
@@ -501,6 +514,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->grp_first, 4 * grp_first.size());
     ALLOC(h->grp_count, 4 * grp_count.size());
     ALLOC(h->gen_list, 4 * gen_list.size());
+    ALLOC(h->wg_jmin, 4 * wg_jmin.size());
 #undef ALLOC
     hipStream_t s = h->stream;
 #define H2D(buf, src, bytes)                                                                               \
@@ -524,6 +538,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->grp_first, grp_first.data(), 4 * grp_first.size());
     H2D(h->grp_count, grp_count.data(), 4 * grp_count.size());
     H2D(h->gen_list, gen_list.data(), 4 * gen_list.size());
+    H2D(h->wg_jmin, wg_jmin.data(), 4 * wg_jmin.size());
 #undef H2D
     HIPCHK(h, hipMemsetAsync(h->dc.p, 0, 8 * d.ld, s));
     HIPCHK(h, hipMemsetAsync(h->dx.p, 0, 24 * N > 0 ? 24 * N : 8, s));
@@ -618,11 +633,18 @@ static int phase_derivatives(srk_ba* h)
     HIPCHK(h, hipMemsetAsync(h->Vg.p, 0, 8 * 9 * d.Ns, s));
     HIPCHK(h, hipMemsetAsync(h->Ug.p, 0, 8 * SRK_UG * (int64_t)d.M, s));
     HIPCHK(h, hipEventRecord(h->ev[12], s));
-    srk_launch_jac_points(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
-                          P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg));
-    HIPCHK(h, hipEventRecord(h->ev[13], s));
-    srk_launch_jac_frames(s, d, h->max_frame_obs, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->col_ptr),
-                          P<int32_t>(h->fobs_pt), P<double>(h->fobs_uv), P<double>(h->Ug));
+    if (h->jac_fused) {
+        srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
+                             P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg),
+                             P<double>(h->Ug), P<int32_t>(h->wg_jmin));
+        HIPCHK(h, hipEventRecord(h->ev[13], s));
+    } else {
+        srk_launch_jac_points(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
+                              P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg));
+        HIPCHK(h, hipEventRecord(h->ev[13], s));
+        srk_launch_jac_frames(s, d, h->max_frame_obs, P<double>(h->pts[c]), P<double>(h->cam[c]),
+                              P<int64_t>(h->col_ptr), P<int32_t>(h->fobs_pt), P<double>(h->fobs_uv), P<double>(h->Ug));
+    }
     HIPCHK(h, hipGetLastError());
     return exchange(h, P<double>(h->Ug), SRK_UG * (int64_t)d.M); // frame blocks + frame gradients over all shards
 }

@@ -74,12 +74,14 @@ __device__ __forceinline__ void obs_pqr(const double* __restrict__ c, double X0,
     g.p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
     g.q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
     g.r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
-    double f0 = c[47];
-    g.ex = g.p / g.r - u / f0;
-    g.ey = g.q / g.r - v / f0;
-    double r2 = g.r * g.r;
-    g.s1 = 2 / r2;
-    g.s2 = 2 / (r2 * g.r * g.r);
+    // one IEEE reciprocal; p/r, q/r, 2/r^2, 2/r^4 and u/f0 become multiplies (<= 1-2 ulp from the divided forms)
+    double ir = 1.0 / g.r;
+    double if0 = c[46];
+    g.ex = g.p * ir - u * if0;
+    g.ey = g.q * ir - v * if0;
+    double ir2 = ir * ir;
+    g.s1 = 2 * ir2;
+    g.s2 = g.s1 * ir2;
 }
 
 // A_v = r p'_v - p r'_v , B_v = r q'_v - q r'_v for the three landmark variables (:1450-1455)
@@ -185,6 +187,137 @@ __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __r
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(&Vg[(int64_t)k * d.Ns + pt], acc[k]);
     }
+}
+
+// ------------------------------------------------------------------ K2 fused: one pass over the observations
+// Same per-observation work as k_jac_points, plus the frame blocks: because landmarks are stored sorted by frame
+// list, the SRK_JF_OBS consecutive observations of a workgroup touch a narrow range of frames; their 55 + 10 frame
+// entries are summed with LDS atomics into per-frame slots (direct-mapped on frame - jmin) and leave the chip once
+// per workgroup.  The host only selects this kernel when every workgroup's frame range fits SRK_JF_SLOTS.
+#define SRK_JF_CHUNKS 4
+#define SRK_JF_OBS (256 * SRK_JF_CHUNKS)
+#define SRK_JF_SLOTS 48
+
+__global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __restrict__ pts,
+                                                   const double* __restrict__ cam,
+                                                   const int32_t* __restrict__ obs_frame,
+                                                   const int32_t* __restrict__ obs_pt,
+                                                   const double* __restrict__ obs_uv, double* __restrict__ W,
+                                                   double* __restrict__ Vg, double* __restrict__ Ug,
+                                                   const int32_t* __restrict__ wg_jmin)
+{
+    __shared__ double sU[SRK_JF_SLOTS][SRK_UG + 1];
+    __shared__ int sTouched[SRK_JF_SLOTS];
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (int t = threadIdx.x; t < SRK_JF_SLOTS * (SRK_UG + 1); t += 256) (&sU[0][0])[t] = 0.0;
+    if (threadIdx.x < SRK_JF_SLOTS) sTouched[threadIdx.x] = 0;
+    const int jmin = wg_jmin[blockIdx.x];
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < SRK_JF_CHUNKS; ++ch) {
+        int64_t o = ((int64_t)blockIdx.x * SRK_JF_CHUNKS + ch) * 256 + threadIdx.x;
+        bool valid = o < d.O;
+        int32_t pt = -1;
+        double acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0;
+        if (valid) {
+            pt = obs_pt[o];
+            int32_t j = obs_frame[o];
+            double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
+            const double* X = pts + 3 * (int64_t)pt;
+            double X0 = X[0], X1 = X[1], X2 = X[2];
+            const double* c = cam + (int64_t)SRK_CAM_PACK * j;
+            ObsGeom g;
+            obs_pqr(c, X0, X1, X2, uv.x, uv.y, g);
+            double Ap[3], Bp[3], Af[10], Bf[10];
+            point_ab(c, g, Ap, Bp);
+            frame_ab(c, g, X0, X1, X2, Af, Bf);
+            // fold 2/r^4 into one side of every product once (saves a multiply per block entry)
+            double Aps[3], Bps[3], Afs[10], Bfs[10];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * g.s2; Bps[v] = Bp[v] * g.s2; }
+#pragma unroll
+            for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * g.s2; Bfs[v] = Bf[v] * g.s2; }
+            double* wp = W + o;
+#ifndef SRK_ABLATE_W
+#pragma unroll
+            for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+                for (int fv = 0; fv < 10; ++fv) {
+                    *wp = Aps[pv] * Af[fv] + Bps[pv] * Bf[fv];
+                    wp += d.Os;
+                }
+#else
+            { double sacc = 0;
+              for (int pv = 0; pv < 3; ++pv) for (int fv = 0; fv < 10; ++fv) sacc += Aps[pv] * Af[fv] + Bps[pv] * Bf[fv];
+              if (sacc == 1.2345) *wp = sacc; }
+#endif
+            acc[0] = Aps[0] * Ap[0] + Bps[0] * Bp[0];
+            acc[1] = Aps[0] * Ap[1] + Bps[0] * Bp[1];
+            acc[2] = Aps[0] * Ap[2] + Bps[0] * Bp[2];
+            acc[3] = Aps[1] * Ap[1] + Bps[1] * Bp[1];
+            acc[4] = Aps[1] * Ap[2] + Bps[1] * Bp[2];
+            acc[5] = Aps[2] * Ap[2] + Bps[2] * Bp[2];
+            double ex1 = g.ex * g.s1, ey1 = g.ey * g.s1;
+            acc[6] = ex1 * Ap[0] + ey1 * Bp[0];
+            acc[7] = ex1 * Ap[1] + ey1 * Bp[1];
+            acc[8] = ex1 * Ap[2] + ey1 * Bp[2];
+            // frame block + frame gradient -> LDS slot of this frame
+            double* su = sU[j - jmin];
+            sTouched[j - jmin] = 1;
+#ifndef SRK_ABLATE_U
+            int idx = 0;
+#pragma unroll
+            for (int v1 = 0; v1 < 10; ++v1)
+#pragma unroll
+                for (int v2 = v1; v2 < 10; ++v2) {
+                    atomicAdd(&su[idx], Afs[v1] * Af[v2] + Bfs[v1] * Bf[v2]);
+                    ++idx;
+                }
+#pragma unroll
+            for (int v = 0; v < 10; ++v) atomicAdd(&su[55 + v], ex1 * Af[v] + ey1 * Bf[v]);
+#else
+            (void)su;
+#endif
+        }
+#ifndef SRK_ABLATE_V
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            int32_t okey = __shfl_down(pt, off, WAVE);
+            bool take = (lane + off < WAVE) && (okey == pt);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                double other = __shfl_down(acc[k], off, WAVE);
+                if (take) acc[k] += other;
+            }
+        }
+        int32_t prev = __shfl_up(pt, 1, WAVE);
+        bool head = (lane == 0) || (prev != pt);
+        if (head && pt >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicAdd(&Vg[(int64_t)k * d.Ns + pt], acc[k]);
+        }
+#else
+        if (acc[0] + acc[4] + acc[8] == 1.2345 && pt >= 0) Vg[pt] = acc[0];
+        (void)lane;
+#endif
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SRK_JF_SLOTS * SRK_UG; t += 256) {
+        int slot = t / SRK_UG, k = t - slot * SRK_UG;
+        if (sTouched[slot]) atomicAdd(&Ug[(int64_t)(jmin + slot) * SRK_UG + k], sU[slot][k]);
+    }
+}
+
+void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
+                          const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
+                          double* Vg, double* Ug, const int32_t* wg_jmin)
+{
+    if (d.O == 0) return;
+    int64_t blocks = (d.O + SRK_JF_OBS - 1) / SRK_JF_OBS;
+    hipLaunchKernelGGL(k_jac_fused, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv, W,
+                       Vg, Ug, wg_jmin);
 }
 
 void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,

@@ -37,6 +37,12 @@ void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double
 void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                            const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
                            double* Vg);
+// fused single pass (point blocks + frame blocks); usable when every workgroup's frame range fits SRK_JF_SLOTS_HOST
+#define SRK_JF_OBS_HOST 1024
+#define SRK_JF_SLOTS_HOST 48
+void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
+                          const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
+                          double* Vg, double* Ug, const int32_t* wg_jmin);
 void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_obs, const double* pts,
                            const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
                            double* Ug);

@@ -1,0 +1,20 @@
+#!/bin/bash
+# development: rebuild libsrk_ba.so with one ablation macro at a time on the GPU box and time the Jacobian phase
+set -e
+cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
+cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
+for abl in NONE SRK_ABLATE_U SRK_ABLATE_W SRK_ABLATE_V "SRK_ABLATE_U -DSRK_ABLATE_V" "SRK_ABLATE_U -DSRK_ABLATE_V -DSRK_ABLATE_W"; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -D$abl -c srk_ba_kernels.hip -o /tmp/k_abl.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so /tmp/k_abl.o srk_chol.o srk_ba_host.o srk_scene.o
+  (cd "$GRAFT_REPO_ROOT" && python - <<PY
+import surikatoko_amd as sa, time
+spec=sa.CONFIGS["C3_1kcam_100kpt"]; sc=sa.generate_scene(spec)
+ba=sa.BundleAdjustmentKanatani(0); ba.upload(spec.f0, sc)
+for _ in range(3): ba.phase_derivatives()
+t=time.perf_counter()
+for _ in range(20): ba.phase_derivatives()
+print("$abl", (time.perf_counter()-t)/20*1e6, "us per derivatives phase (incl. memsets+sync)")
+PY
+)
+done
+cp /tmp/libsrk_ba.so.orig ../libsrk_ba.so
