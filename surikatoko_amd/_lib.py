@@ -66,6 +66,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever is
+    # loaded first serves both, and torch refuses to see the GPU when it is not its own.  Importing torch first makes
+    # device pointers of this library usable by torch.distributed / RCCL (surikatoko_amd/dist.py).  Pure C/C++ users
+    # of libsrk_ba.so never load torch and run on the ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_PATH):
         raise LibraryNotBuilt(
             f"{_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -333,3 +333,65 @@ def test_c2_size_properties(gpu):
     # the gauge leaves a similarity free, so compare through the reprojection error only
     e_final, _ = gpu.ReprojError(spec.f0, out)
     assert e_final == pytest.approx(errs[-1], rel=1e-6)
+
+
+# ------------------------------------------------------------------ sharded path, world size 1 on the GPU
+
+def test_allreduce_hook_with_device_pointers(orc, gpu):
+    """The RCCL path end to end at world size 1: the library packs the skyline, calls the torch.distributed hook with
+    DEVICE pointers (zero-copy __cuda_array_interface__ views) and must give the same iterations as without it."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from surikatoko_amd.ba import covisibility
+    from surikatoko_amd.dist import make_allreduce_hook
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    ref = sc.copy()
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(1e-7)
+    ok_ref = gpu.ComputeInplace(spec.f0, ref, crit, 6)
+    rep_ref = (gpu.report.iterations, gpu.report.attempts, gpu.report.err_final)
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        h = sa.BundleAdjustmentKanatani(0)
+        calls = []
+        inner = make_allreduce_hook(None, "cuda:0")
+
+        from surikatoko_amd._lib import ALLREDUCE_FN
+
+        def counting(ctx, ptr, count):
+            calls.append(int(count))
+            return inner(ctx, ptr, count)
+
+        h.set_allreduce(ALLREDUCE_FN(counting), 0, 1)
+        full = sc.copy()
+        ok, nrm = sa.normalize_scene_inplace(full)
+        assert ok
+        shard, _ = full.shard(0, 1)
+        assert h.upload(spec.f0, shard, already_normalized=True)
+        assert h.rcs_fill() == pytest.approx(1.0, abs=0.35)   # no covisibility given yet: (padded) full triangle
+        h.set_covisibility(covisibility(full))
+        assert 0 < h.rcs_fill() <= 1.0
+        ok_h = h.optimize(crit, 6)
+        out = shard.copy()
+        h.download(out, revert_normalization=False)
+        from surikatoko_amd.ba import revert_normalization
+        revert_normalization(out, nrm)
+        assert ok_h == ok_ref
+        assert (h.report.iterations, h.report.attempts) == rep_ref[:2]
+        assert h.report.err_final == pytest.approx(rep_ref[2], rel=1e-9)
+        assert np.abs(out.points - ref.points).max() < 1e-8
+        # exchanges: seen count, error, frame blocks (65 M), packed skyline, rhs
+        assert 65 * sc.M in calls and 1 in calls
+        h.close()
+    finally:
+        dist.destroy_process_group()
