@@ -54,7 +54,7 @@ struct srk_ba {
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
     std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
-    DevBuf env_col, env_off, packed;
+    DevBuf env_col, env_off, packed, dinv;
     int64_t env_packed = 0;
     bool use_envelope = true;
     int cur = 0; // index of the current scene buffers; 1-cur = trial
@@ -147,7 +147,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
                       &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
                       &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count,
-                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin };
+                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
@@ -515,6 +515,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->grp_count, 4 * grp_count.size());
     ALLOC(h->gen_list, 4 * gen_list.size());
     ALLOC(h->wg_jmin, 4 * wg_jmin.size());
+    ALLOC(h->dinv, 8 * 64 * d.ld);
 #undef ALLOC
     hipStream_t s = h->stream;
 #define H2D(buf, src, bytes)                                                                               \
@@ -695,7 +696,7 @@ static int phase_solve(srk_ba* h, bool profile)
     }
     double* wy = P<double>(h->wy);
     srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info),
-                   h->row_end_h.data(), h->col_begin_h.data(), evs);
+                   h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->dinv), evs);
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
@@ -1089,8 +1090,9 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     int64_t ld = ((n + SRK_CHOL_NB - 1) / SRK_CHOL_NB) * SRK_CHOL_NB;
-    DevBuf dA, dw, dy, dx, dinfo;
+    DevBuf dA, dw, dy, dx, dinfo, ddinv;
     int rc;
+    if ((rc = dev_alloc(h, ddinv, (size_t)(8 * 64 * ld))) != SRK_OK) return rc;
     if ((rc = dev_alloc(h, dA, (size_t)(8 * ld * ld))) != SRK_OK) return rc;
     if ((rc = dev_alloc(h, dw, (size_t)(8 * ld))) != SRK_OK) return rc;
     if ((rc = dev_alloc(h, dy, (size_t)(8 * ld))) != SRK_OK) return rc;
@@ -1107,7 +1109,7 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     HIPCHK(h, hipMemsetAsync(dinfo.p, 0, 4, s));
     HIPCHK(h, hipEventRecord(h->ev[14], s));
     srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr, nullptr,
-                   nullptr);
+                   P<double>(ddinv), nullptr);
     HIPCHK(h, hipEventRecord(h->ev[15], s));
     HIPCHK(h, hipGetLastError());
     int info = 0;
@@ -1120,7 +1122,7 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
         *ms_factor = ms;
     }
     std::memcpy(x, bp.data(), (size_t)(8 * n));
-    dev_free(dA); dev_free(dw); dev_free(dy); dev_free(dx); dev_free(dinfo);
+    dev_free(dA); dev_free(dw); dev_free(dy); dev_free(dx); dev_free(dinfo); dev_free(ddinv);
     return info ? 1 : 0;
 }
 

@@ -42,6 +42,25 @@ __device__ __forceinline__ double fast_rcp(double d)
     return r;
 }
 
+// broadcast lane (4 * quad + K) of every quad to its four lanes: two DPP moves (quad_perm = [K,K,K,K])
+template <int K> __device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_bcast_dyn(double v, int k)
+{
+    switch (k & 3) {
+    case 0: return quad_bcast<0>(v);
+    case 1: return quad_bcast<1>(v);
+    case 2: return quad_bcast<2>(v);
+    default: return quad_bcast<3>(v);
+    }
+}
+
 __device__ __forceinline__ double fast_rsqrt(double d)
 {
     double r = __builtin_amdgcn_rsq(d);
@@ -53,29 +72,50 @@ __device__ __forceinline__ double fast_rsqrt(double d)
 
 // Branch-free inner loop: entries above the diagonal are updated too (never read), so the only per-element
 // predicate left is "column > pivot column" inside the pivot's own group of four.
-__device__ __forceinline__ bool potrf64(double (*sD)[NB + 1], double (*sT)[NB + 2], double* sCol /*[2][64]*/,
-                                        double* sDiag /*[64]*/, double* sInv /*[64]*/)
+__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sCol /*[2][64]*/, double* sDiag /*[64]*/,
+                                        double* sInv /*[64]*/)
 {
     const int t = threadIdx.x, i = t >> 2, q = t & 3;
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = sD[i][4 * m + q];
-    int bad = 0;
+    // pivot health as two running scalars (a per-pivot flag would keep all 64 pivots live until the end):
+    // dmin <= 0 catches non-positive pivots, 0 * d turns Inf / NaN into NaN
+    double dmin = 1.0, dchk = 0.0;
+    // Software-pipelined pivots: inside step j the entry of the NEXT pivot column is updated and published first,
+    // the barrier follows at once, and the other 15 updates of step j run under the LDS latency of column j + 1.
+    if (q == 0) sCol[i] = a[0];
+    __syncthreads();
+    double dj = sCol[0], ci = sCol[i], cc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) cc[m] = sCol[4 * m + q];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double* col = sCol + (j & 1) * NB;
-        if (q == (j & 3)) col[i] = a[j >> 2];
-        __syncthreads();
-        double dj = col[j];
-        bad |= !(dj > 0.0 && dj < 1.0e300);
-        double li = col[i] * fast_rcp(dj);
-        {
-            const int m0 = j >> 2;
-            double f = (q > (j & 3)) ? li : 0.0;
-            a[m0] = fma(-f, col[4 * m0 + q], a[m0]);
+        dmin = fmin(dmin, dj);
+        dchk = fma(0.0, dj, dchk);
+        const double li = ci * fast_rcp(dj);
+        const double lpred = (q > (j & 3)) ? li : 0.0; // inside the pivot's own group of four only columns > j
+        const int m0 = j >> 2, m1 = (j + 1) >> 2;
+        double dn = 0, cin = 0, ccn[16];
+        if (j + 1 < NB) {
+            a[m1] = fma(-(m1 == m0 ? lpred : li), cc[m1], a[m1]);
+            double* coln = sCol + ((j + 1) & 1) * NB;
+            if (q == ((j + 1) & 3)) coln[i] = a[m1];
+            __syncthreads();
+            dn = coln[j + 1];
+            cin = coln[i];
+#pragma unroll
+            for (int m = m1; m < 16; ++m) ccn[m] = coln[4 * m + q];
         }
 #pragma unroll
-        for (int m = (j >> 2) + 1; m < 16; ++m) a[m] = fma(-li, col[4 * m + q], a[m]);
+        for (int m = m0; m < 16; ++m) {
+            if (m == m1 && j + 1 < NB) continue; // already done above
+            a[m] = fma(-(m == m0 ? lpred : li), cc[m], a[m]);
+        }
+        dj = dn;
+        ci = cin;
+#pragma unroll
+        for (int m = m1; m < 16; ++m) cc[m] = ccn[m];
     }
     // the owner of a diagonal entry still holds its pivot d_i (entries are final once their column is passed)
 #pragma unroll
@@ -90,80 +130,127 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 1], double (*sT)[NB + 
         double v = a[m] * sInv[c];          // c < i : a_ic / sqrt(d_c) ; c == i : d_i / sqrt(d_i) = L_ii
         v = (c <= i) ? v : 0.0;
         sD[i][c] = v;
-        sT[c][i] = v; // transposed copy: column j of L contiguous in t for the row sweeps
     }
     __syncthreads();
-    return bad != 0;
+    return !(dmin > 0.0) || (dchk != 0.0);
 }
 
 // ---------------------------------------------------------------- inner panel: potrf + trsm + forward substitution
 // d = index of the 64-wide diagonal tile.  Rows (d+1)*64 .. row_end-1 of columns [64 d, 64 d + 64) become L.
 // w is the running right-hand side: y_d = L_dd^-1 w_d is published to y, and w_r -= L[r, d-cols] . y_d for the
 // rows below (so the forward substitution L y = b costs no extra launches).
+#ifdef SRK_PANEL_STAMPS
+__device__ long long g_panel_stamps[16];
+#define STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d == 40) g_panel_stamps[k] = clock64(); } while (0)
+#else
+#define STAMP(k)
+#endif
+#define PANEL_ROWS 63 // matrix rows per workgroup; the 64th quad carries the right-hand side as one more row
 __global__ __launch_bounds__(256) void k_panel(double* __restrict__ A, int64_t ld, int64_t d, int64_t row_end,
                                                double* __restrict__ w, double* __restrict__ y,
                                                int* __restrict__ info)
 {
-    __shared__ double sD[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double sT[NB][NB + 2];
+    __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
     __shared__ double sCol[2 * NB];
     __shared__ double sDiag[NB];
     __shared__ double sInv[NB];
     __shared__ double sy[NB];
     const int64_t k0 = d * NB;
     double* Ab = A + k0 * ld + k0;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
-        int i = e >> 6, c = e & 63;
-        sD[i][c] = (c <= i) ? Ab[(int64_t)i * ld + c] : 0.0;
+    STAMP(0);
+    {
+        // row i = t >> 2, 16 columns from (t & 3) * 16: eight independent 16-byte loads per thread; entries above the
+        // diagonal are masked by select (never branched on)
+        const int i = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
+        const double2* src = reinterpret_cast<const double2*>(Ab + (int64_t)i * ld + cb);
+        double2 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = src[t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int c = cb + 2 * t;
+            sD[i][c] = (c <= i) ? v[t].x : 0.0;
+            sD[i][c + 1] = (c + 1 <= i) ? v[t].y : 0.0;
+        }
     }
-    if (threadIdx.x < NB) sy[threadIdx.x] = w[k0 + threadIdx.x];
     __syncthreads();
-    bool bad = potrf64(sD, sT, sCol, sDiag, sInv);
+    STAMP(1);
+    bool bad = potrf64(sD, sCol, sDiag, sInv);
+    STAMP(2);
     if (bad && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(info, 1);
     if (blockIdx.x == 0) {
-        for (int e = threadIdx.x; e < NB * NB; e += 256) {
-            int i = e >> 6, c = e & 63;
-            if (c <= i) Ab[(int64_t)i * ld + c] = sD[i][c];
+        const int i = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
+        double2* dst = reinterpret_cast<double2*>(Ab + (int64_t)i * ld + cb);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int c = cb + 2 * t;
+            if (c <= i) dst[t] = make_double2(sD[i][c], sD[i][c + 1]); // the entry above the diagonal is 0, never read
         }
     }
-    // y_d = L_dd^-1 w_d : one wave, lock-step column sweep
-    if (threadIdx.x < NB) {
-        int i = threadIdx.x;
-        double bi = sy[i];
-#pragma unroll 8
-        for (int j = 0; j < NB; ++j) {
-            double yj = __shfl(bi, j, 64) * sInv[j];
-            double lij = (i > j) ? sD[i][j] : 0.0;
-            bi = (i == j) ? yj : fma(-lij, yj, bi);
-        }
-        sy[i] = bi;
-        if (blockIdx.x == 0) y[k0 + i] = bi;
-    }
-    __syncthreads();
-    // rows of the panel: 64 rows per workgroup, a row is split over the 4 lanes of a quad (lane q owns the columns
-    // c = 4m + q, 16 registers) -- 4x the parallelism of a row-per-thread sweep and the same code shape as potrf64
-    const int q = threadIdx.x & 3;
-    int64_t r = k0 + NB + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-    bool live = r < row_end;
-    double* row = A + (live ? r : k0) * ld + k0; // dead rows read the diagonal tile (harmless) and store nothing
+    STAMP(3);
+    // Row sweep X = A[rows, panel] L_dd^-T, four columns at a time.  A row is split over the 4 lanes of a quad (lane q
+    // owns columns c = 4m + q).  Quad 63 carries the right-hand side w_d as one more row: its sweep IS the forward
+    // substitution y_d = L_dd^-1 w_d, at no extra latency.
+    const int q = threadIdx.x & 3, qd = threadIdx.x >> 2;
+    const bool is_rhs = qd == PANEL_ROWS;
+    int64_t r = k0 + NB + (int64_t)blockIdx.x * PANEL_ROWS + qd;
+    const bool live = !is_rhs && r < row_end;
+    double* row = is_rhs ? (w + k0) : (A + (live ? r : k0) * ld + k0); // dead rows read the diagonal tile (harmless)
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = row[4 * m + q];
+#ifdef SRK_PANEL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(4);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+#ifdef SRK_PANEL_STAMPS
+        if (b == 4) STAMP(7);
+        if (b == 8) STAMP(8);
+        if (b == 12) STAMP(9);
+#endif
+        const int c0 = 4 * b;
+        // the four entries of this row in columns c0..c0+3, on every lane of the quad
+        double v0 = quad_bcast<0>(a[b]), v1 = quad_bcast<1>(a[b]), v2 = quad_bcast<2>(a[b]), v3 = quad_bcast<3>(a[b]);
+        // 4x4 lower-triangular solve against L_dd[c0.., c0..]
+        double x0 = v0 * sInv[c0];
+        double x1 = fma(-x0, sD[c0 + 1][c0], v1) * sInv[c0 + 1];
+        double x2 = fma(-x1, sD[c0 + 2][c0 + 1], fma(-x0, sD[c0 + 2][c0], v2)) * sInv[c0 + 2];
+        double x3 = fma(-x2, sD[c0 + 3][c0 + 2], fma(-x1, sD[c0 + 3][c0 + 1], fma(-x0, sD[c0 + 3][c0], v3))) * sInv[c0 + 3];
+        {
+            const double x01 = (q & 1) ? x1 : x0, x23 = (q & 1) ? x3 : x2;
+            a[b] = (q & 2) ? x23 : x01;
+        }
+        // rank-4 update of the columns to the right: a[c] -= sum_k x_k L[c][c0 + k].  The LDS addresses are static, so
+        // without fences the scheduler hoists every read to the top and spills (seen: 256 VGPR + 256 AGPR + scratch);
+        // a fence every four columns keeps <= 8 sixteen-byte reads in flight.
+#pragma unroll
+        for (int m = b + 1; m < 16; ++m) {
+            const double2* lp = reinterpret_cast<const double2*>(&sD[4 * m + q][c0]);
+            double2 l01 = lp[0], l23 = lp[1];
+            a[m] = fma(-x3, l23.y, fma(-x2, l23.x, fma(-x1, l01.y, fma(-x0, l01.x, a[m]))));
+            if (((m - b) & 3) == 0) asm volatile("" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+    }
+    STAMP(5);
+    if (is_rhs) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sy[4 * m + q] = a[m];
+    }
+    __syncthreads();
+    if (is_rhs) {
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) y[k0 + 4 * m + q] = a[m];
+        }
+        return;
+    }
+    // w_r -= L[r, panel] . y_d  (the forward substitution's update of the rows below)
     double dot = 0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        // x_j = a_j / L_jj lives in lane (j & 3) of the quad: broadcast it inside the quad
-        double xo = a[j >> 2] * sInv[j];
-        double x = __shfl(xo, (threadIdx.x & 60) | (j & 3), 64);
-        if (q == (j & 3)) { a[j >> 2] = x; dot = fma(x, sy[j], dot); }
-        {
-            const int m0 = j >> 2;
-            double f = (q > (j & 3)) ? x : 0.0;
-            a[m0] = fma(-f, sT[j][4 * m0 + q], a[m0]);
-        }
-#pragma unroll
-        for (int m = (j >> 2) + 1; m < 16; ++m) a[m] = fma(-x, sT[j][4 * m + q], a[m]);
-    }
+    for (int m = 0; m < 16; ++m) dot = fma(a[m], sy[4 * m + q], dot);
     dot += __shfl_xor(dot, 1, 64);
     dot += __shfl_xor(dot, 2, 64);
     if (live) {
@@ -171,7 +258,11 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ A, int64_t l
         for (int m = 0; m < 16; ++m) row[4 * m + q] = a[m];
         if (q == 0) w[r] -= dot;
     }
+    STAMP(6);
 }
+#ifdef SRK_PANEL_STAMPS
+extern "C" void srk_dbg_panel_stamps(long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_stamps), sizeof(long long) * 16); }
+#endif
 
 // ---------------------------------------------------------------- 64-deep update inside the outer panel (MFMA)
 // A[rt, ct] -= L[rt, d] L[ct, d]^T for row tiles rt > d (rows < row_end) and column tiles d < ct <= c_hi, ct <= rt.
@@ -325,44 +416,139 @@ __global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_
         }
 }
 
+// ---------------------------------------------------------------- trailing update, small-skyline variant
+// Same contraction as k_trail on 64x64 tiles (4x the workgroups, a quarter of the serial work each): when only a few
+// 128-tiles are inside the skyline the update is latency-bound and the grid, not the tile shape, sets its time.
+__global__ __launch_bounds__(256) void k_trail64(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first)
+{
+    __shared__ double sA[NB][LDSP];
+    __shared__ double sB[NB][LDSP];
+    int64_t p = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(ti + 1) * (ti + 2) / 2 <= p) ++ti;
+    while ((int64_t)ti * (ti + 1) / 2 > p) --ti;
+    int tj = (int)(p - (int64_t)ti * (ti + 1) / 2);
+    const int64_t r0 = c_first + (int64_t)ti * NB, c0 = c_first + (int64_t)tj * NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){ 0, 0, 0, 0 };
+    for (int ch = 0; ch < NBO / NB; ++ch) {
+        const double* pa = A + (r0 + row) * ld + k0 + ch * NB + seg;
+        const double* pb = A + (c0 + row) * ld + k0 + ch * NB + seg;
+        double2 va[8], vb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            va[t] = reinterpret_cast<const double2*>(pa)[t];
+            vb[t] = reinterpret_cast<const double2*>(pb)[t];
+        }
+        __syncthreads(); // previous chunk fully consumed
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            sA[row][seg + 2 * t] = va[t].x;
+            sA[row][seg + 2 * t + 1] = va[t].y;
+            sB[row][seg + 2 * t] = vb[t].x;
+            sB[row][seg + 2 * t + 1] = vb[t].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            double a0 = sA[wr * 32 + lr][kk * 4 + lk];
+            double a1 = sA[wr * 32 + 16 + lr][kk * 4 + lk];
+            double b0 = sB[wc * 32 + lr][kk * 4 + lk];
+            double b1 = sB[wc * 32 + 16 + lr][kk * 4 + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                int64_t r = r0 + wr * 32 + m * 16 + lk + 4 * reg;
+                int64_t c = c0 + wc * 32 + n * 16 + lr;
+                double* pc = A + r * ld + c;
+                *pc = *pc - acc[m][n][reg];
+            }
+}
+
 // ---------------------------------------------------------------- backward substitution L^T x = y
-// step d (descending): x_d = L_dd^-T y_d (every workgroup, redundantly), then y_j -= sum_i L[64 d + i, j] x_d[i]
-// for the columns j in [col_begin, 64 d) (col_begin > 0 only for banded / skyline systems).
-__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ A, int64_t ld, int64_t d,
-                                                  int64_t col_begin, double* __restrict__ y, double* __restrict__ x)
+// k_dinv: Dinv[d] = L_dd^-1 (lower triangular, 64x64) for every diagonal tile at once -- it turns the 64 dependent
+// steps of each triangular solve into one small matrix-vector product.
+__global__ __launch_bounds__(64) void k_dinv(const double* __restrict__ A, int64_t ld, double* __restrict__ Dinv)
 {
     __shared__ double sL[NB][NB + 1];
-    __shared__ double sx[NB];
-    __shared__ double sInv[NB];
-    const int64_t k0 = d * NB;
-    const double* Lb = A + k0 * ld + k0;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    __shared__ double sZ[NB][NB + 1];
+    const int64_t k0 = (int64_t)blockIdx.x * NB;
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 64) {
         int i = e >> 6, c = e & 63;
-        sL[i][c] = (c <= i) ? Lb[(int64_t)i * ld + c] : 0.0;
+        sL[i][c] = (c <= i) ? A[(k0 + i) * ld + k0 + c] : 0.0;
     }
-    if (threadIdx.x < NB) sx[threadIdx.x] = y[k0 + threadIdx.x];
     __syncthreads();
-    if (threadIdx.x < NB) sInv[threadIdx.x] = 1.0 / sL[threadIdx.x][threadIdx.x];
+    // thread t: column t of L^-1 by forward substitution (z_i = (e_t[i] - sum_{m<i} L_im z_m) / L_ii); the sums run
+    // in lock step over (i, m), so L_im is an LDS broadcast and z_m[t] is bank-conflict free
+    for (int i = 0; i < NB; ++i) {
+        double sum = (i == t) ? 1.0 : 0.0;
+        for (int m = 0; m < i; ++m) sum -= sL[i][m] * ((m >= t) ? sZ[m][t] : 0.0);
+        sZ[i][t] = (i >= t) ? sum / sL[i][i] : 0.0;
+    }
     __syncthreads();
-    if (threadIdx.x < NB) {
-        int i = threadIdx.x;
-        double bi = sx[i];
+    double* out = Dinv + (int64_t)blockIdx.x * NB * NB;
+    for (int e = t; e < NB * NB; e += 64) out[e] = sZ[e >> 6][e & 63];
+}
+
+// step K (descending, 256 rows): x_K = L_KK^-T y_K by four tile back-substitutions with the explicit tile inverses
+// (every workgroup, redundantly), then y_j -= sum_i L[256 K + i, j] x_K[i] for this workgroup's columns
+// j in [col_begin, 256 K).
+__global__ __launch_bounds__(256) void k_bwd256(const double* __restrict__ A, int64_t ld, int64_t K, int64_t col_begin,
+                                                const double* __restrict__ Dinv, double* __restrict__ y,
+                                                double* __restrict__ x)
+{
+    __shared__ double sv[NBO];
+    const int64_t k0 = K * NBO;
+    const int t = threadIdx.x;
+    sv[t] = y[k0 + t];
+    __syncthreads();
+    for (int sub = NBO / NB - 1; sub >= 0; --sub) {
+        // x_sub = Dinv_sub^T v_sub : thread (i = t >> 2, q = t & 3) sums m = q, q+4, ... then the quad reduces
+        const double* D = Dinv + (K * (NBO / NB) + sub) * NB * NB;
+        int i = t >> 2, q = t & 3;
+        double part = 0;
+#pragma unroll 4
+        for (int m = q; m < NB; m += 4) part += D[m * NB + i] * sv[sub * NB + m];
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        __syncthreads();
+        if (q == 0) sv[sub * NB + i] = part;
+        __syncthreads();
+        // v_c -= sum_i L[tile sub, col c] x_sub[i] for the columns c of the earlier tiles of this 256 block
+        if (t < sub * NB) {
+            const double* Lr = A + (k0 + sub * NB) * ld + k0 + t;
+            double acc = 0;
 #pragma unroll 8
-        for (int j = NB - 1; j >= 0; --j) {
-            double xj = __shfl(bi, j, 64) * sInv[j];
-            double lji = (i < j) ? sL[j][i] : 0.0; // (L^T)[i][j] = L[j][i]
-            bi = (i == j) ? xj : fma(-lji, xj, bi);
+            for (int r = 0; r < NB; ++r) acc += Lr[(int64_t)r * ld] * sv[sub * NB + r];
+            sv[t] -= acc;
         }
-        sx[i] = bi;
-        if (blockIdx.x == 0) x[k0 + i] = bi;
+        __syncthreads();
     }
-    __syncthreads();
-    int64_t j = col_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) x[k0 + t] = sv[t];
+    int64_t j = col_begin + (int64_t)blockIdx.x * 256 + t;
     if (j >= k0) return;
-    double s = 0;
+    const double* Lc = A + k0 * ld + j;
+    double acc = 0;
 #pragma unroll 8
-    for (int i = 0; i < NB; ++i) s += A[(k0 + i) * ld + j] * sx[i];
-    y[j] -= s;
+    for (int r = 0; r < NBO; ++r) acc += Lc[(int64_t)r * ld] * sv[r];
+    y[j] -= acc;
 }
 
 // the solution must be all finite (the reference's allFinite check, :1912-1913)
@@ -375,9 +561,10 @@ __global__ __launch_bounds__(256) void k_check_finite(int64_t n, const double* _
 // w: right-hand side (destroyed).  y: scratch (forward solution).  x: solution.
 // row_end[K] (host, one per outer panel, multiple of 128, > 256 (K+1) or == ld): rows >= row_end[K] have no
 // non-zero in the panel's columns and are skipped; NULL = dense.  col_begin[d64] (host, per 64-tile, may be NULL):
-// first column with a non-zero in tile row d64.  ev_pairs: optional 2 events per outer panel around k_trail.
+// first column with a non-zero in tile row d64.  dinv: scratch, (ld / 64) * 64 * 64 doubles (inverses of the
+// diagonal tiles).  ev_pairs: optional 2 events per outer panel around the trailing update.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
-                    const int64_t* row_end, const int64_t* col_begin, hipEvent_t* ev_pairs)
+                    const int64_t* row_end, const int64_t* col_begin, double* dinv, hipEvent_t* ev_pairs)
 {
     const int64_t nout = ld / NBO;
     for (int64_t K = 0; K < nout; ++K) {
@@ -388,7 +575,7 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
         for (int jsub = 0; jsub < NBO / NB; ++jsub) {
             int64_t d = K * (NBO / NB) + jsub;
             int64_t rows = rend - (d + 1) * NB;
-            int64_t blocks = rows > 0 ? (rows + 63) / 64 : 1;
+            int64_t blocks = rows > 0 ? (rows + PANEL_ROWS - 1) / PANEL_ROWS : 1;
             hipLaunchKernelGGL(k_panel, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, d, rend, w, y, d_info);
             int64_t c_hi = K * (NBO / NB) + (NBO / NB - 1);
             if (jsub < NBO / NB - 1 && rows > 0) {
@@ -400,19 +587,24 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
         int64_t c_first = k0 + NBO;
         int64_t T = (rend - c_first) / TL;
         if (ev_pairs) hipEventRecord(ev_pairs[2 * K], s);
-        if (T > 0) {
+        if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
+            int64_t T64 = 2 * T;
+            hipLaunchKernelGGL(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2)), dim3(256), 0, s, A, ld, k0, c_first);
+        } else if (T > 0) {
             int64_t pairs = T * (T + 1) / 2;
             hipLaunchKernelGGL(k_trail, dim3((unsigned)pairs), dim3(256), 0, s, A, ld, k0, c_first);
         }
         if (ev_pairs) hipEventRecord(ev_pairs[2 * K + 1], s);
     }
-    const int64_t n64 = ld / NB;
-    for (int64_t d = n64 - 1; d >= 0; --d) {
-        int64_t cb = col_begin ? col_begin[d] : 0;
-        if (cb > d * NB) cb = d * NB;
-        int64_t cols = d * NB - cb;
+    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(ld / NB)), dim3(64), 0, s, A, ld, dinv);
+    for (int64_t K = nout - 1; K >= 0; --K) {
+        int64_t cb = col_begin ? col_begin[K * (NBO / NB)] : 0;
+        for (int q = 1; q < NBO / NB; ++q)
+            if (col_begin) cb = cb < col_begin[K * (NBO / NB) + q] ? cb : col_begin[K * (NBO / NB) + q];
+        if (cb > K * NBO) cb = K * NBO;
+        int64_t cols = K * NBO - cb;
         int64_t blocks = cols > 0 ? (cols + 255) / 256 : 1;
-        hipLaunchKernelGGL(k_bwd_step, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, d, cb, y, x);
+        hipLaunchKernelGGL(k_bwd256, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, K, cb, dinv, y, x);
     }
     hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }

@@ -77,5 +77,5 @@ void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, cons
 // info (device int) is set non-zero when a pivot is not positive/finite or the solution is not finite.
 // row_end / col_begin: optional host arrays describing the skyline of A (see srk_chol.hip); NULL = dense.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
-                    const int64_t* row_end, const int64_t* col_begin,
+                    const int64_t* row_end, const int64_t* col_begin, double* dinv /* (ld / 64) * 4096 doubles */,
                     hipEvent_t* ev_pairs /* 2 * (ld / SRK_CHOL_NB) events or NULL */);

@@ -1,0 +1,25 @@
+#!/bin/bash
+# development: in-kernel clock stamps of k_panel (d = 40, last workgroup) on the GPU box
+set -e
+cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
+cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DSRK_PANEL_STAMPS -c srk_chol.hip -o /tmp/chol_st.o 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so srk_ba_kernels.o /tmp/chol_st.o srk_ba_host.o srk_scene.o
+(cd "$GRAFT_REPO_ROOT" && python - <<'PY'
+import ctypes as C, numpy as np
+import surikatoko_amd as sa
+spec=sa.CONFIGS["C3_1kcam_100kpt"]; sc=sa.generate_scene(spec)
+ba=sa.BundleAdjustmentKanatani(0); ba.upload(spec.f0, sc)
+for _ in range(2):
+    ba.reset(); ba.optimize(None, max_iterations=1)
+out=(C.c_longlong*16)()
+sa.lib().srk_dbg_panel_stamps(out)
+t=[out[i] for i in range(7)]
+names=["load diag","potrf64","store+fwd","row load","row sweep","row store"]
+print("clock64 ticks (100 MHz => x10 ns):")
+for n,a,b in zip(names,t[:-1],t[1:]): print(f"  {n:12s} {b-a:8d} ticks = {(b-a)*10/1000:.2f} us")
+print("  sweep quarters:", out[7]-out[4], out[8]-out[7], out[9]-out[8], out[5]-out[9])
+print("  total", (t[-1]-t[0])*10/1000, "us")
+PY
+)
+cp /tmp/libsrk_ba.so.orig ../libsrk_ba.so

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-kernel average HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; units KiB... see below).
+
+MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read
+-> doubled here; WRITE_SIZE is exact for 16-B/lane streaming stores and float atomics.  rocprofv3 reports both in
+units of 1 KiB? -> we read the raw counter value column and print bytes = value * 1024 (guide section 7)."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+
+def load(d):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0]
+            acc[name][0] += float(r["Counter_Value"])
+            acc[name][1] += 1
+    return acc
+
+
+fe, wr = load(sys.argv[1]), load(sys.argv[2])
+print(f"{'kernel':28s} {'calls':>6s} {'fetch_MB(x2 corr)':>18s} {'write_MB':>10s} {'total_MB/launch':>16s}")
+for k in sorted(fe, key=lambda k: -fe[k][0]):
+    n = max(fe[k][1], 1)
+    f_mb = 2.0 * fe[k][0] * 1024 / n / 1e6
+    w_mb = wr.get(k, [0, 1])[0] * 1024 / max(wr.get(k, [0, 1])[1], 1) / 1e6
+    print(f"{k[:28]:28s} {n:6d} {f_mb:18.2f} {w_mb:10.2f} {f_mb + w_mb:16.2f}")
