@@ -551,8 +551,11 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     const double* __restrict__ W, const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count)
 {
-    __shared__ __attribute__((aligned(16))) double sW[SRK_GRP_PB][SRK_GRP_MAXNF * 30];
-    __shared__ __attribute__((aligned(16))) double sY[SRK_GRP_PB][SRK_GRP_MAXNF * 30];
+    // one LDS arena: W | Y staging during the accumulation, then the staging buffer of the coalesced flush
+    __shared__ __attribute__((aligned(16))) double sBuf[2 * SRK_GRP_PB * SRK_GRP_MAXNF * 30];
+    double (*sW)[SRK_GRP_MAXNF * 30] = reinterpret_cast<double (*)[SRK_GRP_MAXNF * 30]>(sBuf);
+    double (*sY)[SRK_GRP_MAXNF * 30] =
+        reinterpret_cast<double (*)[SRK_GRP_MAXNF * 30]>(sBuf + SRK_GRP_PB * SRK_GRP_MAXNF * 30);
     __shared__ double sE[SRK_GRP_PB][12];
     __shared__ int32_t sF[SRK_GRP_MAXNF];
     const int tid = threadIdx.x;
@@ -644,22 +647,40 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
             }
         }
     }
-    // flush: S -= sum F^T E^-1 F (lower block triangle), rhs += sum F^T E^-1 g, gauge rows/columns dropped
+    // flush: S -= sum F^T E^-1 F (lower block triangle), rhs += sum F^T E^-1 g, gauge rows/columns dropped.
+    // The register strips are transposed through LDS a few block rows at a time so that consecutive lanes add to
+    // consecutive columns of one row of S (block row a = 10 rows of 10 (a + 1) doubles, contiguous when the frames
+    // are) -- a wave-wide atomic then covers whole cache lines instead of 64 different rows.
+    constexpr int CAP = 2 * SRK_GRP_PB * SRK_GRP_MAXNF * 30;
+    for (int a0 = 0; a0 < nf;) {
+        int a1 = a0, used = 0;
+        while (a1 < nf && used + 100 * (a1 + 1) <= CAP) { used += 100 * (a1 + 1); ++a1; }
+        __syncthreads();
 #pragma unroll
-    for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
-        if (!act[s]) continue;
-        int64_t rowb = 10 * (int64_t)sF[sa[s]] + sr[s], colb = 10 * (int64_t)sF[sb[s]];
+        for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+            if (!act[s] || sa[s] < a0 || sa[s] >= a1) continue;
+            int off = 50 * (sa[s] * (sa[s] + 1) - a0 * (a0 + 1)); // sum_{a'=a0}^{a-1} 100 (a' + 1)
+            int w = 10 * (sa[s] + 1);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t row = rowb + i;
-            if (srk_is_fixed_var(row, d.comp)) continue;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int cc = 0; cc < 10; ++cc) {
-                int64_t col = colb + cc;
-                if (srk_is_fixed_var(col, d.comp)) continue;
-                atomicAdd(&S[row * d.ld + col], -acc[s][i][cc]);
-            }
+                for (int cc = 0; cc < 10; ++cc) sBuf[off + (sr[s] + i) * w + 10 * sb[s] + cc] = acc[s][i][cc];
         }
+        __syncthreads();
+        for (int e = tid; e < used; e += SRK_GRP_THREADS) {
+            // e -> block row a (off_a <= e < off_{a+1}), row r, block b, column c
+            int a = (int)((sqrtf(1.0f + 4.0f * ((float)e / 50.0f + (float)(a0 * (a0 + 1)))) - 1.0f) * 0.5f);
+            while (50 * ((a + 1) * (a + 2) - a0 * (a0 + 1)) <= e) ++a;
+            while (50 * (a * (a + 1) - a0 * (a0 + 1)) > e) --a;
+            int rem = e - 50 * (a * (a + 1) - a0 * (a0 + 1));
+            int w = 10 * (a + 1);
+            int r = rem / w, cw = rem - r * w;
+            int b = cw / 10, cc = cw - b * 10;
+            int64_t row = 10 * (int64_t)sF[a] + r, col = 10 * (int64_t)sF[b] + cc;
+            if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
+            atomicAdd(&S[row * d.ld + col], -sBuf[e]);
+        }
+        a0 = a1;
     }
     if (tid < nf * 10) {
         int a = tid / 10, r = tid - a * 10;
