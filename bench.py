@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--config", default="C3_1kcam_100kpt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
+    ap.add_argument("--no-dense-probe", action="store_true")
     ap.add_argument("--rcs", choices=["skyline", "dense"], default="skyline",
                     help="reduced-camera-system solver: exploit the covisibility skyline (exact) or treat it as dense")
     return ap.parse_args()
@@ -153,6 +154,18 @@ def main():
     err_final = ba.report.err_final
     err_initial = ba.report.err_initial
 
+    # outside the timed region: one more step with the reduced camera system treated as DENSE, so that every bench
+    # line carries the fp64-MFMA trailing update at full size (the north-star's "dense RCS GEMM" evidence)
+    dense_probe = None
+    if world == 1 and args.rcs == "skyline" and not args.no_dense_probe:
+        ba.set_rcs_mode(False)
+        dflops = ba.solve_mfma_flops()
+        step()
+        r = step()
+        dense_probe = {"ms_solve": r.ms_solve / max(r.attempts, 1), "ms_trail": r.ms_solve_syrk / max(r.attempts, 1),
+                       "flops": dflops}
+        ba.set_rcs_mode(True)
+
     if rank == 0:
         K = max(args.steps, 1)
         ms_per_step = 1e3 * dt / K
@@ -161,17 +174,32 @@ def main():
         per_it = {k: v / K for k, v in acc.items()}
         per_attempt = {k: v / max(attempts, 1) for k, v in acc.items()}
 
-        def hbm(bytes_, ms):
+        # HBM traffic per launch from the committed PMC passes of this configuration (profiles/, rocprofv3 --pmc in
+        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH x2 correction); None when no profile matches
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r1", f"pmc_{args.config}.json")
+        if world == 1 and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))["kernels"]
+            except Exception:
+                pmc = {}
+
+        def traffic(*names):
+            vals = [pmc[n]["hbm_bytes_per_launch"] for n in names if n in pmc]
+            return sum(vals) if vals else None
+
+        def hbm(bytes_, ms, *kernel_names):
             a = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                    "traffic": None, "ms": ms, "algorithmic_bytes": bytes_}
+                    "traffic": traffic(*kernel_names), "ms": ms, "algorithmic_bytes": bytes_}
 
         kernels = {
-            "jacobian_phase": hbm(ab["jacobian"], per_it["ms_jacobian"]),
-            "jacobian_point_kernel": hbm(ab["jacobian"] - M * 880, per_it["ms_jacobian_kernel"]),
-            "schur_phase": hbm(ab["schur"], per_attempt["ms_schur"]),
-            "backsub_phase": hbm(ab["backsub"], per_attempt["ms_backsub"]),
-            "error_phase": hbm(ab["error"], per_attempt["ms_error"]),
+            "jacobian_phase": hbm(ab["jacobian"], per_it["ms_jacobian"], "k_jac_fused"),
+            "jacobian_kernel": hbm(ab["jacobian"], per_it["ms_jacobian_kernel"], "k_jac_fused"),
+            "schur_phase": hbm(ab["schur"], per_attempt["ms_schur"], "k_schur_grouped", "k_schur", "k_env_zero",
+                               "k_assemble"),
+            "backsub_phase": hbm(ab["backsub"], per_attempt["ms_backsub"], "k_backsub_obs", "k_point_update"),
+            "error_phase": hbm(ab["error"], per_attempt["ms_error"], "k_error"),
         }
         ms_syrk = per_attempt["ms_solve_syrk"]
         # flops actually executed by the MFMA trailing-update launches (= n^3/3 up to blocking when dense)
@@ -182,6 +210,17 @@ def main():
                                       "dense_flops_n3_over_3": ab["solve_flops"],
                                       "ms_solve_phase": per_attempt["ms_solve"], "rcs_mode": args.rcs,
                                       "rcs_fill": rcs_fill}
+        if dense_probe and dense_probe["ms_trail"] > 0:
+            tfd = dense_probe["flops"] / (dense_probe["ms_trail"] * 1e-3) / 1e12
+            kernels["solve_trail_mfma_dense_probe"] = {
+                "bound": "mfma", "achieved": tfd, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tfd / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "ms": dense_probe["ms_trail"],
+                "algorithmic_flops": dense_probe["flops"], "ms_solve_phase": dense_probe["ms_solve"],
+                "note": "one untimed step with the reduced camera system forced dense (--rcs dense gives the same)"}
+        kernels["solve_panel_chain"] = {
+            "bound": "latency", "ms": per_attempt["ms_solve"] - per_attempt["ms_solve_syrk"],
+            "note": "sequential 64-column panel kernels + backward substitution of the blocked Cholesky: a dependency "
+                    "chain of n pivots, bound by per-pivot latency, not by HBM or MFMA throughput"}
         # dominant kernel = the phase with the largest share of the step
         shares = {"jacobian_phase": per_it["ms_jacobian"], "schur_phase": per_it["ms_schur"],
                   "solve_syrk_mfma": per_it["ms_solve"], "backsub_phase": per_it["ms_backsub"]}

@@ -8,4 +8,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $out
   timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -- python bench.py --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log || { tail -5 $out/err.log; exit 1; }
 done
-python tools/pmc_summary.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE
+python tools/pmc_summary.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/pmc_${tag}.json
