@@ -426,19 +426,6 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     }
     h->n_groups = (int64_t)grp_first.size();
     h->n_generic = (int64_t)gen_list.size();
-    // frame range of every SRK_JF_OBS_HOST-observation workgroup of the fused Jacobian kernel
-    std::vector<int32_t> wg_jmin;
-    h->jac_fused = true;
-    for (int64_t o0 = 0; o0 < O; o0 += SRK_JF_OBS_HOST) {
-        int32_t lo = obs_frame[o0], hi = obs_frame[o0];
-        for (int64_t o = o0; o < std::min<int64_t>(O, o0 + SRK_JF_OBS_HOST); ++o) {
-            lo = std::min(lo, obs_frame[o]);
-            hi = std::max(hi, obs_frame[o]);
-        }
-        if (hi - lo >= SRK_JF_SLOTS_HOST) h->jac_fused = false;
-        wg_jmin.push_back(lo);
-    }
-
     SrkDims d{};
     d.N = N;
     d.M = M;
@@ -476,6 +463,22 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             fobs_uv[(size_t)(2 * k + 1)] = obs_uv[2 * o + 1];
         }
     }
+
+    // frame range of every SRK_JF_OBS_HOST-observation workgroup of the fused Jacobian kernel
+    std::vector<int32_t> wg_jmin;
+    h->jac_fused = true;
+    for (int64_t o0 = 0; o0 < O; o0 += SRK_JF_OBS_HOST) {
+        int32_t lo = obs_frame[o0], hi = obs_frame[o0];
+        for (int64_t o = o0; o < std::min<int64_t>(O, o0 + SRK_JF_OBS_HOST); ++o) {
+            lo = std::min(lo, obs_frame[o]);
+            hi = std::max(hi, obs_frame[o]);
+        }
+        if (hi - lo >= SRK_JF_SLOTS_HOST) h->jac_fused = false;
+        int64_t olast = std::min<int64_t>(O, o0 + SRK_JF_OBS_HOST) - 1;
+        if (obs_pt[(size_t)olast] - obs_pt[(size_t)o0] + 1 > SRK_JF_PMAX_HOST) h->jac_fused = false;
+        wg_jmin.push_back(lo);
+    }
+
 
 #define ALLOC(buf, bytes)                              \
     do {                                               \

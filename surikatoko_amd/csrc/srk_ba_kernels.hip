@@ -198,6 +198,16 @@ __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __r
 #define SRK_JF_OBS (256 * SRK_JF_CHUNKS)
 #define SRK_JF_SLOTS 48
 
+#define SRK_JF_PMAX 448 // landmarks per workgroup held in LDS (host falls back to the two-kernel path beyond)
+
+__device__ __forceinline__ double jf_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __restrict__ pts,
                                                    const double* __restrict__ cam,
                                                    const int32_t* __restrict__ obs_frame,
@@ -206,41 +216,82 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
                                                    double* __restrict__ Vg, double* __restrict__ Ug,
                                                    const int32_t* __restrict__ wg_jmin)
 {
-    __shared__ double sU[SRK_JF_SLOTS][SRK_UG + 1];
+    __shared__ double sU[SRK_JF_SLOTS][SRK_UG + 1];                              // frame blocks + frame gradients
+    __shared__ __attribute__((aligned(16))) double sCam[SRK_JF_SLOTS][SRK_CAM_PACK]; // camera packs of the frame range
+    __shared__ double sV[9][SRK_JF_PMAX];                                        // point blocks + point gradients
     __shared__ int sTouched[SRK_JF_SLOTS];
     const int lane = threadIdx.x & (WAVE - 1);
-    for (int t = threadIdx.x; t < SRK_JF_SLOTS * (SRK_UG + 1); t += 256) (&sU[0][0])[t] = 0.0;
-    if (threadIdx.x < SRK_JF_SLOTS) sTouched[threadIdx.x] = 0;
     const int jmin = wg_jmin[blockIdx.x];
+    const int64_t o_first = (int64_t)blockIdx.x * SRK_JF_OBS;
+    const int64_t o_last = (o_first + SRK_JF_OBS < d.O ? o_first + SRK_JF_OBS : d.O) - 1;
+    const int32_t pmin = obs_pt[o_first], pmax = obs_pt[o_last];
+    const int npts = pmax - pmin + 1;
+    for (int t = threadIdx.x; t < SRK_JF_SLOTS * (SRK_UG + 1); t += 256) (&sU[0][0])[t] = 0.0;
+    for (int t = threadIdx.x; t < 9 * SRK_JF_PMAX; t += 256) (&sV[0][0])[t] = 0.0;
+    if (threadIdx.x < SRK_JF_SLOTS) sTouched[threadIdx.x] = 0;
+    {
+        int nfr = d.M - jmin < SRK_JF_SLOTS ? d.M - jmin : SRK_JF_SLOTS;
+        const double* src = cam + (int64_t)SRK_CAM_PACK * jmin;
+        for (int t = threadIdx.x; t < nfr * SRK_CAM_PACK; t += 256) (&sCam[0][0])[t] = src[t];
+    }
     __syncthreads();
 #pragma unroll 1
     for (int ch = 0; ch < SRK_JF_CHUNKS; ++ch) {
-        int64_t o = ((int64_t)blockIdx.x * SRK_JF_CHUNKS + ch) * 256 + threadIdx.x;
-        bool valid = o < d.O;
+        const int64_t o = o_first + ch * 256 + threadIdx.x;
+        const bool valid = o < d.O;
         int32_t pt = -1;
         double acc[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] = 0;
         if (valid) {
             pt = obs_pt[o];
-            int32_t j = obs_frame[o];
+            const int js = obs_frame[o] - jmin;
             double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
             const double* X = pts + 3 * (int64_t)pt;
-            double X0 = X[0], X1 = X[1], X2 = X[2];
-            const double* c = cam + (int64_t)SRK_CAM_PACK * j;
-            ObsGeom g;
-            obs_pqr(c, X0, X1, X2, uv.x, uv.y, g);
+            const double X0 = X[0], X1 = X[1], X2 = X[2];
+            const double* c = sCam[js];
+            // (p, q, r) = K (R X + T)   (:469-470)
+            const double xc0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+            const double xc1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+            const double xc2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+            const double p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
+            const double q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
+            const double r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
+            const double ir = jf_rcp(r), ir2 = ir * ir;
+            const double s1 = 2 * ir2, s2 = s1 * ir2; // 2 / r^2 , 2 / r^4
+            const double ex1 = (p * ir - uv.x * c[46]) * s1, ey1 = (q * ir - uv.y * c[46]) * s1;
+            // A_v = r p'_v - p r'_v , B_v = r q'_v - q r'_v
             double Ap[3], Bp[3], Af[10], Bf[10];
-            point_ab(c, g, Ap, Bp);
-            frame_ab(c, g, X0, X1, X2, Af, Bf);
-            // fold 2/r^4 into one side of every product once (saves a multiply per block entry)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                Ap[v] = r * c[21 + v] - p * c[27 + v];
+                Bp[v] = r * c[24 + v] - q * c[27 + v];
+            }
+            const double g_uv = c[46] * r * r;
+            Af[0] = r * (c[42] * p - c[43] * r); Bf[0] = 0;
+            Af[1] = 0;                           Bf[1] = r * (c[44] * q - c[45] * r);
+            Af[2] = g_uv;                        Bf[2] = 0;
+            Af[3] = 0;                           Bf[3] = g_uv;
+            // translation and rotation columns share a1 = r rot1 - p rot3, b1 = r rot2 - q rot3 :
+            //   d/dT = -(a1, b1)   (:1503-1505)      d/dW = (a1 x t, b1 x t), t = X - T_direct   (:1511-1520)
+            double a1[3], b1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a1[k] = r * c[33 + k] - p * c[39 + k];
+                b1[k] = r * c[36 + k] - q * c[39 + k];
+                Af[4 + k] = -a1[k];
+                Bf[4 + k] = -b1[k];
+            }
+            const double t0 = X0 - c[30], t1 = X1 - c[31], t2 = X2 - c[32];
+            Af[7] = a1[1] * t2 - a1[2] * t1; Af[8] = a1[2] * t0 - a1[0] * t2; Af[9] = a1[0] * t1 - a1[1] * t0;
+            Bf[7] = b1[1] * t2 - b1[2] * t1; Bf[8] = b1[2] * t0 - b1[0] * t2; Bf[9] = b1[0] * t1 - b1[1] * t0;
+            // fold 2/r^4 into one side of every product once
             double Aps[3], Bps[3], Afs[10], Bfs[10];
 #pragma unroll
-            for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * g.s2; Bps[v] = Bp[v] * g.s2; }
+            for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * s2; Bps[v] = Bp[v] * s2; }
 #pragma unroll
-            for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * g.s2; Bfs[v] = Bf[v] * g.s2; }
+            for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * s2; Bfs[v] = Bf[v] * s2; }
             double* wp = W + o;
-#ifndef SRK_ABLATE_W
 #pragma unroll
             for (int pv = 0; pv < 3; ++pv)
 #pragma unroll
@@ -248,25 +299,18 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
                     *wp = Aps[pv] * Af[fv] + Bps[pv] * Bf[fv];
                     wp += d.Os;
                 }
-#else
-            { double sacc = 0;
-              for (int pv = 0; pv < 3; ++pv) for (int fv = 0; fv < 10; ++fv) sacc += Aps[pv] * Af[fv] + Bps[pv] * Bf[fv];
-              if (sacc == 1.2345) *wp = sacc; }
-#endif
             acc[0] = Aps[0] * Ap[0] + Bps[0] * Bp[0];
             acc[1] = Aps[0] * Ap[1] + Bps[0] * Bp[1];
             acc[2] = Aps[0] * Ap[2] + Bps[0] * Bp[2];
             acc[3] = Aps[1] * Ap[1] + Bps[1] * Bp[1];
             acc[4] = Aps[1] * Ap[2] + Bps[1] * Bp[2];
             acc[5] = Aps[2] * Ap[2] + Bps[2] * Bp[2];
-            double ex1 = g.ex * g.s1, ey1 = g.ey * g.s1;
             acc[6] = ex1 * Ap[0] + ey1 * Bp[0];
             acc[7] = ex1 * Ap[1] + ey1 * Bp[1];
             acc[8] = ex1 * Ap[2] + ey1 * Bp[2];
-            // frame block + frame gradient -> LDS slot of this frame
-            double* su = sU[j - jmin];
-            sTouched[j - jmin] = 1;
-#ifndef SRK_ABLATE_U
+            // frame block (55 unique) + frame gradient (10) -> LDS slot of this frame (few lanes share a frame)
+            double* su = sU[js];
+            sTouched[js] = 1;
             int idx = 0;
 #pragma unroll
             for (int v1 = 0; v1 < 10; ++v1)
@@ -277,11 +321,9 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
                 }
 #pragma unroll
             for (int v = 0; v < 10; ++v) atomicAdd(&su[55 + v], ex1 * Af[v] + ey1 * Bf[v]);
-#else
-            (void)su;
-#endif
         }
-#ifndef SRK_ABLATE_V
+        // point block + gradient: wavefront segmented reduction over the landmark's (contiguous) observations, then
+        // one LDS add per (wave, landmark) -- 20 lanes adding to one LDS word would serialise (measured slower)
 #pragma unroll
         for (int off = 1; off < WAVE; off <<= 1) {
             int32_t okey = __shfl_down(pt, off, WAVE);
@@ -293,17 +335,21 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
             }
         }
         int32_t prev = __shfl_up(pt, 1, WAVE);
-        bool head = (lane == 0) || (prev != pt);
-        if (head && pt >= 0) {
+        if (((lane == 0) || (prev != pt)) && pt >= 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) atomicAdd(&Vg[(int64_t)k * d.Ns + pt], acc[k]);
+            for (int k = 0; k < 9; ++k) atomicAdd(&sV[k][pt - pmin], acc[k]);
         }
-#else
-        if (acc[0] + acc[4] + acc[8] == 1.2345 && pt >= 0) Vg[pt] = acc[0];
-        (void)lane;
-#endif
     }
     __syncthreads();
+    // landmarks strictly inside the workgroup's range are complete: plain coalesced stores; the first and the last
+    // may continue in the neighbouring workgroups: atomics
+    for (int t = threadIdx.x; t < 9 * npts; t += 256) {
+        int k = t / npts, ps = t - k * npts;
+        double v = sV[k][ps];
+        double* dst = &Vg[(int64_t)k * d.Ns + pmin + ps];
+        if (ps == 0 || ps == npts - 1) atomicAdd(dst, v);
+        else *dst = v;
+    }
     for (int t = threadIdx.x; t < SRK_JF_SLOTS * SRK_UG; t += 256) {
         int slot = t / SRK_UG, k = t - slot * SRK_UG;
         if (sTouched[slot]) atomicAdd(&Ug[(int64_t)(jmin + slot) * SRK_UG + k], sU[slot][k]);

@@ -40,6 +40,7 @@ void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, c
 // fused single pass (point blocks + frame blocks); usable when every workgroup's frame range fits SRK_JF_SLOTS_HOST
 #define SRK_JF_OBS_HOST 1024
 #define SRK_JF_SLOTS_HOST 48
+#define SRK_JF_PMAX_HOST 448
 void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                           const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
                           double* Vg, double* Ug, const int32_t* wg_jmin);
