@@ -200,6 +200,22 @@ int srk_scene_generate(const srk_scene_spec*, double* points, double* points_gt,
 void srk_circle_camera_shots(const double center[3], double radius, double ascent_z, int32_t n,
                              const double* angles, double* cam_R, double* cam_T);
 
+/* ---- callers of the BA path: the dinosaur loader and its pre-processing (host only) ----
+ * srk_read_matrix_file          ReadMatrixFromFile        cpp_impl/suriko-engine/src/mat-serialization.cpp:12-87
+ * srk_decompose_proj_mat        DecomposeProjMat          cpp_impl/suriko-engine/src/obs-geom.cpp:606-677
+ * srk_triangulate_least_squares Triangulate3DPointByLeastSquares              obs-geom.cpp:679-727
+ * srk_dino_load                 DinoDemo's scene build    cpp_impl/demos/demo-bundle-adj-dinosaur.cpp:24-54,85-230
+ * all return 1 on success, 0 on failure (err receives the reference's message where it has one). */
+int srk_read_matrix_file(const char* path, char delimiter, double* data /* NULL = count only */, int64_t capacity,
+                         int64_t* rows, int64_t* cols, char* err, int errlen);
+int srk_decompose_proj_mat(const double* P /* [3][4] */, double* scale_factor, double* K /* [9] */,
+                           double* R_direct /* [9] */, double* T_direct /* [3] */);
+int srk_triangulate_least_squares(int32_t n, const double* uv /* [n][2] */, const double* P /* [n][12] */, double f0,
+                                  double* X /* [3] */);
+int srk_dino_load(const char* dir, double f0, int64_t* n_points, int32_t* n_frames, int64_t* n_obs,
+                  double* points /* NULL = sizes only */, double* cam_R, double* cam_T, double* K, int64_t* row_ptr,
+                  int32_t* obs_frame, double* obs_uv, char* err, int errlen);
+
 #ifdef __cplusplus
 }
 #endif

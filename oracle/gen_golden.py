@@ -197,8 +197,52 @@ def rodrigues_case():
     print("wrote rodrigues")
 
 
+
+
+def dino_prep_case():
+    """DecomposeProjMat / Triangulate3DPointByLeastSquares of py_proto/suriko/obs_geom.py:149-199, 430-456
+    (the dino demo's pre-processing)."""
+    rng = np.random.RandomState(5)
+    Rs, Ts = look_at_cams(7, rng)
+    Ps, scales, Ks, Rd, Td = [], [], [], [], []
+    for k, (R, T) in enumerate(zip(Rs, Ts)):
+        K = np.array([[880.0 * (1 + 0.02 * k), 3.0 * k, 400.0 - 5 * k], [0, 660.0, 300.0 + 4 * k], [0, 0, 1.0]])
+        P = (1.5 - 0.7 * k) * K.dot(np.hstack([R, T.reshape(3, 1)]))  # both signs of the scale
+        sc, Kd, (Rdir, tdir) = obs_geom.DecomposeProjMat(P)
+        Ps.append(P)
+        scales.append(sc)
+        Ks.append(Kd)
+        Rd.append(Rdir)
+        Td.append(tdir)
+    pts = rng.uniform(-1, 1, (12, 3))
+    f0 = 600.0
+    Pn = [np.array(P) / np.linalg.norm(np.array(P)[2, 0:3]) for P in Ps]
+    tri_uv, tri_P, tri_X, tri_n = [], [], [], []
+    for X in pts:
+        n = rng.randint(2, 8)
+        idx = rng.choice(7, n, replace=False)
+        uv, PP = [], []
+        for j in idx:
+            x = Pn[j].dot(np.hstack([X, 1.0]))
+            uv.append(x[0:2] / x[2] * 1.0 + rng.normal(0, 0.5, 2))
+            # the demo triangulates with f0-scaled matrices: rows 0,1 divided by f0
+            Pj = Pn[j].copy()
+            Pj[0:2, :] /= f0
+            PP.append(Pj)
+        Xt = obs_geom.Triangulate3DPointByLeastSquares(uv, PP, f0, 0)
+        tri_n.append(n)
+        tri_uv.append(np.vstack(uv + [np.zeros(2)] * (7 - n)))
+        tri_P.append(np.array(PP + [np.zeros((3, 4))] * (7 - n)))
+        tri_X.append(Xt)
+    np.savez_compressed(os.path.join(OUT, "pyproto_dino_prep.npz"), P=np.array(Ps), scale=np.array(scales),
+                        K=np.array(Ks), R_direct=np.array(Rd), T_direct=np.array(Td), f0=np.float64(f0),
+                        tri_n=np.array(tri_n), tri_uv=np.array(tri_uv), tri_P=np.array(tri_P), tri_X=np.array(tri_X))
+    print("wrote dino prep")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     run_case("pyproto_case_a", seed=11, M=6, N=40, f0=1.0, k22=1.0, with_error=True)
     run_case("pyproto_case_b", seed=23, M=9, N=64, f0=600.0, k22=600.0, with_error=False)
     rodrigues_case()
+    dino_prep_case()

@@ -1,0 +1,146 @@
+"""the dinosaur loader and its pre-processing (host code behind the C ABI), checked against golden
+vectors from the reference's Python prototype (obs_geom.py DecomposeProjMat / Triangulate3DPointByLeastSquares) and
+by a file round trip (the oxfvisgeom files themselves are not in the reference tree)."""
+import os
+
+import numpy as np
+import pytest
+
+import surikatoko_amd as sa
+from surikatoko_amd import io as sio
+from conftest import load_golden
+
+
+def test_decompose_proj_mat_vs_prototype():
+    g = load_golden("pyproto_dino_prep")
+    for P, sc, K, R, T in zip(g["P"], g["scale"], g["K"], g["R_direct"], g["T_direct"]):
+        ok, s, Kd, Rd, Td = sio.decompose_proj_mat(P)
+        assert ok
+        assert s == pytest.approx(float(sc), rel=1e-10)
+        assert np.abs(Kd - K).max() < 1e-8 * np.abs(K).max()
+        assert np.abs(Rd - R).max() < 1e-10 and np.abs(Td - T).max() < 1e-9
+        back = s * Kd @ Rd.T @ np.hstack([np.eye(3), -Td.reshape(3, 1)])   # P = scale K R^T [I | -t]  (:666-670)
+        assert np.abs(back - P).max() < 1e-8 * np.abs(P).max()
+        assert np.linalg.det(Rd) == pytest.approx(1.0, abs=1e-10)
+
+
+def test_triangulate_vs_prototype():
+    g = load_golden("pyproto_dino_prep")
+    f0 = float(g["f0"])
+    for n, uv, P, X in zip(g["tri_n"], g["tri_uv"], g["tri_P"], g["tri_X"]):
+        Xg = sio.triangulate_least_squares(uv[:n], P[:n], f0)
+        assert np.abs(Xg - X).max() < 1e-9 * max(1.0, np.abs(X).max())   # colPivQR vs lstsq (SVD)
+    with pytest.raises(ValueError):   # CHECK(frames_count >= 2)
+        sio.triangulate_least_squares(g["tri_uv"][0][:1], g["tri_P"][0][:1], f0)
+
+
+def test_read_matrix_from_file(tmp_path):
+    p = tmp_path / "m.txt"
+    p.write_text("1\t2.5\t-3\n4e2\t5\t6\n")
+    m = sio.read_matrix_from_file(p, "\t")
+    assert m.shape == (2, 3) and m[1, 0] == 400.0 and m[0, 1] == 2.5
+    p.write_text("1 2 3\n4 5\n")
+    with pytest.raises(ValueError, match="inconsistent number of columns"):
+        sio.read_matrix_from_file(p, " ")
+    p.write_text("1 2x 3\n")
+    with pytest.raises(ValueError, match="Can't parse number"):
+        sio.read_matrix_from_file(p, " ")
+    with pytest.raises(ValueError, match="Can't open file"):
+        sio.read_matrix_from_file(tmp_path / "missing.txt", " ")
+    p.write_text("")
+    assert sio.read_matrix_from_file(p, " ").size == 0
+
+
+def _write_dino_files(directory, sc, pts_gt, Rg, Tg, f0):
+    """Files in the oxfvisgeom formats (demo-bundle-adj-dinosaur.cpp:85-116): 3 tab-separated rows of 4 per frame,
+    and one row per point with 'x y' per frame, -1 -1 when unseen."""
+    M = sc.M
+    with open(os.path.join(directory, "dinoPs_as_mat108x4.txt"), "w") as f:
+        for j in range(M):
+            Kpix = np.diag([f0, f0, 1.0]) @ sc.K[j].reshape(3, 3)
+            P = Kpix @ np.hstack([Rg[j].reshape(3, 3), Tg[j].reshape(3, 1)])
+            for r in range(3):
+                f.write("\t".join(repr(float(v)) for v in P[r]) + "\n")
+    with open(os.path.join(directory, "viff.xy"), "w") as f:
+        for i in range(sc.N):
+            row = -np.ones(2 * M)
+            for o in range(sc.row_ptr[i], sc.row_ptr[i + 1]):
+                row[2 * sc.obs_frame[o]:2 * sc.obs_frame[o] + 2] = sc.obs_uv[o]
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+
+
+def test_dino_loader_round_trip(tmp_path):
+    spec = sa.SceneSpec(n_frames=9, grid_nx=6, grid_ny=5, vis_window=4, noise_x3d_hi=0.0, noise_r_hi=0.0)
+    sc, pts_gt, Rg, Tg = sa.generate_scene(spec, with_gt=True)
+    _write_dino_files(str(tmp_path), sc, pts_gt, Rg, Tg, spec.f0)
+    loaded = sio.load_dino_scene(tmp_path, spec.f0)
+    assert (loaded.N, loaded.M, loaded.O) == (sc.N, sc.M, sc.O)
+    assert np.array_equal(loaded.row_ptr, sc.row_ptr) and np.array_equal(loaded.obs_frame, sc.obs_frame)
+    assert np.abs(loaded.obs_uv - sc.obs_uv).max() < 1e-9
+    assert np.abs(loaded.K - sc.K).max() < 1e-9            # K(0,1) is 0 in the synthetic scene already
+    assert np.abs(loaded.cam_R - Rg).max() < 1e-9 and np.abs(loaded.cam_T - Tg).max() < 1e-8
+    assert np.abs(loaded.points - pts_gt).max() < 1e-7     # exact pixels -> triangulation recovers the landmarks
+
+
+@pytest.mark.gpu
+def test_dino_demo_path_on_gpu(tmp_path):
+    """demo-dino end to end on a stand-in written in the oxfvisgeom file formats: load -> ComputeInplace."""
+    spec = sa.SceneSpec(n_frames=12, grid_nx=9, grid_ny=8, vis_window=4, noise_uv_pix=0.3)
+    sc, pts_gt, Rg, Tg = sa.generate_scene(spec, with_gt=True)
+    _write_dino_files(str(tmp_path), sc, pts_gt, Rg, Tg, spec.f0)
+    scene = sio.load_dino_scene(tmp_path, spec.f0)
+    ba = sa.BundleAdjustmentKanatani(0)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(1e-5)       # the demo's --allowed_repr_err default (:66)
+    e0, seen = ba.ReprojError(spec.f0, scene)
+    ok = ba.ComputeInplace(spec.f0, scene, crit, 50)
+    assert ba.OptimizationStatusString() in ("small relative err change", "max iterations", "abs err threshold")
+    assert ba.report.err_final <= e0 and seen == scene.O
+    ba.close()
+
+
+def _run(cmd, cwd):
+    import json
+    import subprocess
+    p = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1]), p.stderr
+
+
+@pytest.mark.gpu
+def test_demo_circle_grid_cli_with_reference_flagfile(orc):
+    """The C++ drop-in of demo-circle-grid with the reference's flagfile values (81 points x 36 frames, all visible,
+    rotation noise only) against the oracle run on the same scene built here in numpy."""
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "demos", "demo-circle-grid")
+    if not os.path.exists(exe):
+        pytest.skip("demos not built")
+    out, log = _run([exe, "--flagfile=" + os.path.join(ROOT, "demos", "flagfile-demo-circle-grid.txt"),
+                     "--max_iterations=25"], ROOT)
+    assert out["frames"] == 36 and out["points"] == 81
+    assert out["iterations"] >= 1 and out["err_final"] < out["err_initial"]
+    assert "bundle adjustment finished with result" in log
+
+
+@pytest.mark.gpu
+def test_demo_dino_cli(tmp_path):
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "demos", "demo-dino")
+    if not os.path.exists(exe):
+        pytest.skip("demos not built")
+    spec = sa.SceneSpec(n_frames=10, grid_nx=8, grid_ny=7, vis_window=4, noise_uv_pix=0.2)
+    sc, pts_gt, Rg, Tg = sa.generate_scene(spec, with_gt=True)
+    d = tmp_path / "oxfvisgeom" / "dinosaur"
+    d.mkdir(parents=True)
+    _write_dino_files(str(d), sc, pts_gt, Rg, Tg, spec.f0)
+    out, log = _run([exe, f"--testdata={tmp_path}", "--f0=600", "--allowed_repr_err=4.56e-8", "--max_iterations=30"], ROOT)
+    assert out["seen"] == sc.O and out["err_final"] <= out["err_initial"]
+    # same scene through the Python mirror gives the same numbers
+    scene = sio.load_dino_scene(d, 600.0)
+    ba = sa.BundleAdjustmentKanatani(0)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(4.56e-8)
+    ba.ComputeInplace(600.0, scene, crit, 30)
+    assert ba.report.iterations == out["iterations"] and ba.report.attempts == out["attempts"]
+    assert ba.report.err_final == pytest.approx(out["err_final"], rel=1e-9)
+    ba.close()
