@@ -1,0 +1,78 @@
+// Runtime test of include/suriko_amd/bundle-adj-kanatani.hpp (the C++ mirror of the reference class) in the
+// multi-view-factorization call contract (cpp_impl/suriko-engine/src/multi-view-factorization.cpp:379-394):
+// shared K, f0 = 1, threshold 1e-3, salient points created OUT of track order (pnt_ind follows the tracks,
+// coordinates are fetched by salient-point id, bundle-adj-kanatani.cpp:1161-1171), tracks with gaps and one
+// track without a salient point.  The same flat scene goes through the C ABI directly; both must agree exactly.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "suriko_amd/bundle-adj-kanatani.hpp"
+using namespace suriko_amd;
+
+int main()
+{
+    srk_scene_spec spec{};
+    spec.n_frames = 9; spec.grid_nx = 7; spec.grid_ny = 6; spec.vis_window = 5;
+    spec.half_extent_x = spec.half_extent_y = 1; spec.f0 = 1.0; spec.noise_x3d_hi = 0.005; spec.noise_r_hi = 0.005;
+    spec.noise_uv_pix = 0; spec.seed = 1234;
+    const int64_t N = 42, O = srk_scene_num_observations(&spec);
+    const int32_t M = spec.n_frames;
+    std::vector<double> pts(3 * N), R(9 * M), T(3 * M), K(9 * M), uv(2 * O);
+    std::vector<int64_t> row_ptr(N + 1);
+    std::vector<int32_t> fr(O);
+    if (srk_scene_generate(&spec, pts.data(), nullptr, R.data(), T.data(), nullptr, nullptr, K.data(), row_ptr.data(),
+                           fr.data(), uv.data()) != 0) return 10;
+
+    // containers: salient points are added in REVERSE order of the tracks
+    FragmentMap map;
+    std::vector<size_t> id_of_point((size_t)N);
+    for (int64_t i = N - 1; i >= 0; --i) id_of_point[(size_t)i] = map.AddSalientPoint({ pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] });
+    CornerTrackRepository rep;
+    for (int64_t i = 0; i < N; ++i) {
+        if (i == 5) rep.AddCornerTrackObj().AddCorner(0, { 1.0, 2.0 }); // a track that has no salient point yet
+        CornerTrack& t = rep.AddCornerTrackObj();
+        t.SalientPointId = id_of_point[(size_t)i];
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o) t.AddCorner((size_t)fr[o], { uv[2 * o], uv[2 * o + 1] });
+    }
+    std::vector<SE3Transform> cams((size_t)M);
+    for (int32_t j = 0; j < M; ++j) {
+        for (int e = 0; e < 9; ++e) cams[(size_t)j].R[(size_t)e] = R[9 * j + e];
+        cams[(size_t)j].T = { T[3 * j], T[3 * j + 1], T[3 * j + 2] };
+    }
+    Matrix3 sharedK;
+    for (int e = 0; e < 9; ++e) sharedK[(size_t)e] = K[e];
+    BundleAdjustmentKanataniTermCriteria crit;
+    crit.AllowedReprojErrRelativeChange(1e-3);
+    BundleAdjustmentKanatani ba;
+    size_t seen = 0;
+    double e0 = ba.ReprojError(1.0, map, cams, rep, &sharedK, nullptr, &seen);
+    bool ok = ba.ComputeInplace(1.0, map, cams, rep, &sharedK, nullptr, crit);
+
+    // reference run through the C ABI on the flat arrays
+    srk_ba* h = srk_ba_create(0);
+    srk_ba_report repc;
+    double thr = 1e-3;
+    int rc = srk_ba_compute_inplace(h, 1.0, N, pts.data(), M, R.data(), T.data(), K.data(), 1, row_ptr.data(), fr.data(),
+                                    uv.data(), &thr, nullptr, 0, &repc);
+    if (rc < 0) return 11;
+    double maxd = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const Point3& p = map.GetSalientPoint(id_of_point[(size_t)i]);
+        maxd = std::fmax(maxd, std::fabs(p.x - pts[3 * i]));
+        maxd = std::fmax(maxd, std::fabs(p.y - pts[3 * i + 1]));
+        maxd = std::fmax(maxd, std::fabs(p.z - pts[3 * i + 2]));
+    }
+    for (int32_t j = 0; j < M; ++j)
+        for (int e = 0; e < 9; ++e) maxd = std::fmax(maxd, std::fabs(cams[(size_t)j].R[(size_t)e] - R[9 * j + e]));
+    std::printf("{\"ok\": %d, \"rc\": %d, \"status\": \"%s\", \"seen\": %zu, \"err0\": %.17g, \"err0_c\": %.17g, "
+                "\"err_final\": %.17g, \"err_final_c\": %.17g, \"iterations\": %lld, \"iterations_c\": %lld, \"maxdiff\": %.3e, "
+                "\"points\": %zu, \"vars\": %zu, \"normalized_vars\": %zu}\n",
+                (int)ok, rc, ba.OptimizationStatusString().c_str(), seen, e0, repc.err_initial, ba.Report().err_final,
+                repc.err_final, (long long)ba.Report().iterations, (long long)repc.iterations, maxd, ba.PointsCount(),
+                ba.VarsCount(), ba.NormalizedVarsCount());
+    bool caught = false;
+    try { ba.ComputeInplace(1.0, map, cams, rep, nullptr, nullptr, crit); } catch (const std::invalid_argument&) { caught = true; }
+    srk_ba_destroy(h);
+    return caught ? 0 : 12;
+}

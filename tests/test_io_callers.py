@@ -144,3 +144,20 @@ def test_demo_dino_cli(tmp_path):
     assert ba.report.iterations == out["iterations"] and ba.report.attempts == out["attempts"]
     assert ba.report.err_final == pytest.approx(out["err_final"], rel=1e-9)
     ba.close()
+
+
+@pytest.mark.gpu
+def test_cpp_adapter_mvf_call_contract():
+    """the C++ mirror class in the multi-view-factorization call contract (shared K, f0 = 1,
+    threshold 1e-3, salient points created out of track order) equals the flat C-ABI call."""
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "demos", "test-adapter")
+    if not os.path.exists(exe):
+        pytest.skip("adapter test not built")
+    out, _ = _run([exe], ROOT)
+    assert out["ok"] == (out["rc"] == 0)
+    assert out["seen"] == 42 * 5 and out["points"] == 42 and out["vars"] == 3 * 42 + 90 and out["normalized_vars"] == out["vars"] - 7
+    assert out["err0"] == pytest.approx(out["err0_c"], rel=1e-12)
+    assert out["iterations"] == out["iterations_c"]
+    assert out["err_final"] == pytest.approx(out["err_final_c"], rel=1e-9)
+    assert out["maxdiff"] < 1e-9
