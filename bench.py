@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
     ap.add_argument("--no-dense-probe", action="store_true")
-    ap.add_argument("--rcs", choices=["skyline", "dense"], default="skyline",
+    ap.add_argument("--rcs", choices=["chunks", "skyline", "dense"], default="chunks",
                     help="reduced-camera-system solver: exploit the covisibility skyline (exact) or treat it as dense")
     return ap.parse_args()
 
@@ -112,13 +112,15 @@ def main():
         from surikatoko_amd.dist import make_allreduce_hook
         ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
     assert ba.upload(spec.f0, shard, already_normalized=True)
-    if args.rcs == "dense":
-        ba.set_rcs_mode(False)
-    elif world > 1:
+    RCS_MODE = {"dense": 0, "skyline": 1, "chunks": 2}
+    if args.rcs != "chunks":
+        ba.set_rcs_mode(RCS_MODE[args.rcs])
+    if args.rcs != "dense" and world > 1:
         from surikatoko_amd.ba import covisibility
         ba.set_covisibility(covisibility(scene))  # global skyline: every rank factorises the same all-reduced system
     rcs_fill = ba.rcs_fill()
     mfma_flops = ba.solve_mfma_flops()
+    rcs_chunks = ba.rcs_chunks()
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,14 +159,21 @@ def main():
     # outside the timed region: one more step with the reduced camera system treated as DENSE, so that every bench
     # line carries the fp64-MFMA trailing update at full size (the north-star's "dense RCS GEMM" evidence)
     dense_probe = None
-    if world == 1 and args.rcs == "skyline" and not args.no_dense_probe:
-        ba.set_rcs_mode(False)
+    chain_probe = None
+    if world == 1 and args.rcs != "dense" and not args.no_dense_probe:
+        ba.set_rcs_mode(0)
         dflops = ba.solve_mfma_flops()
         step()
         r = step()
         dense_probe = {"ms_solve": r.ms_solve / max(r.attempts, 1), "ms_trail": r.ms_solve_syrk / max(r.attempts, 1),
                        "flops": dflops}
-        ba.set_rcs_mode(True)
+        if rcs_chunks >= 2:  # the same skyline factorised as ONE panel chain, for the chunking gain
+            ba.set_rcs_mode(1)
+            step()
+            r = step()
+            chain_probe = {"ms_solve": r.ms_solve / max(r.attempts, 1),
+                           "ms_trail": r.ms_solve_syrk / max(r.attempts, 1)}
+        ba.set_rcs_mode(RCS_MODE[args.rcs])
 
     if rank == 0:
         K = max(args.steps, 1)
@@ -202,6 +211,11 @@ def main():
             "error_phase": hbm(ab["error"], per_attempt["ms_error"], "k_error"),
         }
         ms_syrk = per_attempt["ms_solve_syrk"]
+        chunked = rcs_chunks >= 2 and args.rcs == "chunks"
+        if chunked:
+            # chunks factorise concurrently on their own streams: there is no per-launch event pair to sum, so the MFMA
+            # rate is priced against the WHOLE solve phase (a lower bound of the trailing-update kernels' own rate)
+            ms_syrk = per_attempt["ms_solve"]
         # flops actually executed by the MFMA trailing-update launches (= n^3/3 up to blocking when dense)
         tf = mfma_flops / (ms_syrk * 1e-3) / 1e12 if ms_syrk > 0 else 0.0
         kernels["solve_syrk_mfma"] = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -209,7 +223,11 @@ def main():
                                       "ms": ms_syrk, "algorithmic_flops": mfma_flops,
                                       "dense_flops_n3_over_3": ab["solve_flops"],
                                       "ms_solve_phase": per_attempt["ms_solve"], "rcs_mode": args.rcs,
-                                      "rcs_fill": rcs_fill}
+                                      "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks}
+        if chain_probe:
+            kernels["solve_single_chain_probe"] = {
+                "bound": "latency", "ms_solve_phase": chain_probe["ms_solve"], "ms_trail": chain_probe["ms_trail"],
+                "note": "one untimed step with the skyline factorised as one panel chain (--rcs skyline)"}
         if dense_probe and dense_probe["ms_trail"] > 0:
             tfd = dense_probe["flops"] / (dense_probe["ms_trail"] * 1e-3) / 1e12
             kernels["solve_trail_mfma_dense_probe"] = {
@@ -218,7 +236,7 @@ def main():
                 "algorithmic_flops": dense_probe["flops"], "ms_solve_phase": dense_probe["ms_solve"],
                 "note": "one untimed step with the reduced camera system forced dense (--rcs dense gives the same)"}
         kernels["solve_panel_chain"] = {
-            "bound": "latency", "ms": per_attempt["ms_solve"] - per_attempt["ms_solve_syrk"],
+            "bound": "latency", "ms": per_attempt["ms_solve"] - (0.0 if chunked else per_attempt["ms_solve_syrk"]),
             "note": "sequential 64-column panel kernels + backward substitution of the blocked Cholesky: a dependency "
                     "chain of n pivots, bound by per-pivot latency, not by HBM or MFMA throughput"}
         # dominant kernel = the phase with the largest share of the step
@@ -245,7 +263,7 @@ def main():
                                    "iteration per step from the same uploaded state",
                        "parallelism": f"landmark shards x{world}" if world > 1 else "single GPU",
                        "points_per_rank": shard.N, "obs_per_rank": shard.O, "rcs_dim": 10 * M - 7,
-                       "rcs_solver": args.rcs, "rcs_fill": rcs_fill},
+                       "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks},
             "attempts_per_iteration": attempts / max(iterations, 1),
             "ms_per_iter": {"jacobian": per_it["ms_jacobian"], "schur": per_it["ms_schur"],
                             "solve": per_it["ms_solve"], "backsub": per_it["ms_backsub"],

@@ -167,7 +167,9 @@ int srk_ba_download(srk_ba*, int which, double* dst, int64_t count);
  * outside that skyline (exact: Cholesky fill stays inside it).  With landmark shards every rank must be given the
  * GLOBAL covisibility after upload: min_cv[j] = smallest frame index sharing a landmark with frame j. */
 int srk_ba_set_covisibility(srk_ba*, const int32_t* min_cv /* [M], NULL = dense */);
-int srk_ba_set_rcs_mode(srk_ba*, int use_envelope /* 0 = dense lower triangle, 1 = skyline (default) */);
+int srk_ba_set_rcs_mode(srk_ba*, int mode /* 0 = dense lower triangle, 1 = skyline as one chain,
+                                              2 = skyline cut into independent chunks + separator system (default) */);
+int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one chain) */
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
 double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current skyline) */
 

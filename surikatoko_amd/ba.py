@@ -251,8 +251,14 @@ class BundleAdjustmentKanatani:
             a = np.ascontiguousarray(min_cv, dtype=np.int32)
             self._raise(self._lib.srk_ba_set_covisibility(C.c_void_p(self._h), _p(a)))
 
-    def set_rcs_mode(self, use_envelope=True):
-        self._raise(self._lib.srk_ba_set_rcs_mode(C.c_void_p(self._h), C.c_int(int(use_envelope))))
+    def set_rcs_mode(self, mode=2):
+        """0 / False = dense, 1 = skyline as one chain, 2 / True = skyline cut into chunks (default)."""
+        if mode is True:
+            mode = 2
+        self._raise(self._lib.srk_ba_set_rcs_mode(C.c_void_p(self._h), C.c_int(int(mode))))
+
+    def rcs_chunks(self):
+        return int(self._lib.srk_ba_rcs_chunks(C.c_void_p(self._h)))
 
     def solve_mfma_flops(self):
         return float(self._lib.srk_ba_solve_mfma_flops(C.c_void_p(self._h)))

@@ -57,6 +57,12 @@ struct srk_ba {
     DevBuf env_col, env_off, packed, dinv;
     int64_t env_packed = 0;
     bool use_envelope = true;
+    // chunked solve of a banded system (srk_chol.hip): plan + its buffers + the chunk streams
+    bool use_chunks = true;
+    SrkChunkPlan plan;
+    std::vector<DevBuf> plan_bufs;
+    hipStream_t chunk_streams[SRK_MAX_CHUNKS]{};
+    hipEvent_t chunk_events[SRK_MAX_CHUNKS + 2]{};
     int cur = 0; // index of the current scene buffers; 1-cur = trial
 
     // multi-GPU exchange
@@ -135,6 +141,16 @@ srk_ba* srk_ba_create(int device_id)
             delete h;
             return nullptr;
         }
+    for (auto& cs : h->chunk_streams)
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return nullptr;
+        }
+    for (auto& e : h->chunk_events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            delete h;
+            return nullptr;
+        }
     return h;
 }
 
@@ -149,6 +165,11 @@ void srk_ba_destroy(srk_ba* h)
                       &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count,
                       &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv };
     for (DevBuf* b : all) dev_free(*b);
+    for (DevBuf& b : h->plan_bufs) dev_free(b);
+    for (auto& cs : h->chunk_streams)
+        if (cs) hipStreamDestroy(cs);
+    for (auto& e : h->chunk_events)
+        if (e) hipEventDestroy(e);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : h->chol_ev) hipEventDestroy(e);
@@ -303,6 +324,90 @@ static int compute_cam_packs(srk_ba* h, int which)
     return SRK_OK;
 }
 
+// Chunked solve plan: P chunks of the variable range separated by P-1 separators at least as wide as the
+// bandwidth (so chunks are decoupled).  Used when the skyline is narrow and the system is large enough.
+static int build_chunk_plan(srk_ba* h)
+{
+    const SrkDims& d = h->d;
+    SrkChunkPlan& pl = h->plan;
+    pl.P = 0;
+    for (DevBuf& b : h->plan_bufs) dev_free(b);
+    h->plan_bufs.clear();
+    if (!h->use_envelope || !h->use_chunks) return SRK_OK;
+    int64_t maxdist = 0;
+    for (int32_t j = 0; j < d.M; ++j) maxdist = std::max<int64_t>(maxdist, 10 * (int64_t)(j - h->min_cv[(size_t)j]) + 9);
+    int64_t sepw = maxdist <= 256 ? 256 : (maxdist <= 512 ? 512 : 0);
+    if (sepw == 0) return SRK_OK;
+    int P = (int)std::min<int64_t>(SRK_MAX_CHUNKS, d.ld / 1536);
+    while (P >= 2 && (d.ld - sepw * (P - 1)) / P < 2 * sepw) --P; // chunks at least two separators wide
+    if (P < 2) return SRK_OK;
+    const int64_t interior = d.ld - sepw * (P - 1);
+    const int64_t blocks = interior / SRK_CHOL_NB; // interior is a multiple of 256 (ld and sepw are)
+    pl.sepw = sepw;
+    pl.lds = sepw * (P - 1);
+    std::vector<int64_t> sep_start((size_t)(P - 1));
+    int64_t pos = 0;
+    auto alloc = [&](size_t bytes, bool zero) -> void* {
+        h->plan_bufs.emplace_back();
+        if (dev_alloc(h, h->plan_bufs.back(), bytes) != SRK_OK) return nullptr;
+        if (zero) hipMemsetAsync(h->plan_bufs.back().p, 0, bytes, h->stream);
+        return h->plan_bufs.back().p;
+    };
+    for (int c = 0; c < P; ++c) {
+        int64_t nb = blocks / P + (c < blocks % P ? 1 : 0);
+        pl.a[c] = pos;
+        pl.n[c] = nb * SRK_CHOL_NB;
+        pl.ldc[c] = pl.n[c] + 2 * sepw;
+        pos += pl.n[c];
+        if (c < P - 1) {
+            sep_start[(size_t)c] = pos;
+            pos += sepw;
+        }
+        const int64_t nc = pl.n[c], ldc = pl.ldc[c];
+        pl.Ac[c] = (double*)alloc((size_t)(8 * ldc * ldc), true);
+        pl.wc[c] = (double*)alloc((size_t)(8 * ldc), true);
+        pl.yc[c] = (double*)alloc((size_t)(8 * ldc), true);
+        pl.xc[c] = (double*)alloc((size_t)(8 * ldc), true);
+        pl.dinvc[c] = (double*)alloc((size_t)(8 * 64 * ldc), false);
+        if (!pl.Ac[c] || !pl.wc[c] || !pl.yc[c] || !pl.xc[c] || !pl.dinvc[c]) return SRK_E_NOMEM;
+        pl.row_end[c].assign((size_t)(nc / SRK_CHOL_NB), 0);
+        for (int64_t K = 0; K < nc / SRK_CHOL_NB; ++K) {
+            int64_t rg = h->row_end_h[(size_t)(pl.a[c] / SRK_CHOL_NB + K)] - pl.a[c];
+            pl.row_end[c][(size_t)K] = std::min<int64_t>(std::max<int64_t>(rg, SRK_CHOL_NB * (K + 1)), nc);
+        }
+        pl.col_begin[c].assign((size_t)(nc / 64), 0);
+        for (int64_t q = 0; q < nc / 64; ++q)
+            pl.col_begin[c][(size_t)q] = std::max<int64_t>(h->col_begin_h[(size_t)(pl.a[c] / 64 + q)] - pl.a[c], 0);
+        pl.streams[c] = h->chunk_streams[c];
+        pl.ev_join[c] = h->chunk_events[c];
+    }
+    pl.ev_fork = h->chunk_events[SRK_MAX_CHUNKS];
+    pl.ev_fork2 = h->chunk_events[SRK_MAX_CHUNKS + 1];
+    const int64_t lds = pl.lds;
+    pl.Cs = (double*)alloc((size_t)(8 * lds * lds), true);
+    pl.ws = (double*)alloc((size_t)(8 * lds), true);
+    pl.ys = (double*)alloc((size_t)(8 * lds), true);
+    pl.xs = (double*)alloc((size_t)(8 * lds), true);
+    pl.dinvs = (double*)alloc((size_t)(8 * 64 * lds), false);
+    pl.d_sep_start = (int64_t*)alloc((size_t)(8 * (P - 1)), false);
+    if (!pl.Cs || !pl.ws || !pl.ys || !pl.xs || !pl.dinvs || !pl.d_sep_start) return SRK_E_NOMEM;
+    HIPCHK(h, hipMemcpyAsync(pl.d_sep_start, sep_start.data(), (size_t)(8 * (P - 1)), hipMemcpyHostToDevice, h->stream));
+    // separators only couple with their neighbours (through the chunk between them): block tridiagonal skyline
+    pl.s_row_end.assign((size_t)(lds / SRK_CHOL_NB), 0);
+    for (int64_t K = 0; K < lds / SRK_CHOL_NB; ++K) {
+        int64_t c = (SRK_CHOL_NB * K) / sepw;
+        pl.s_row_end[(size_t)K] = std::min<int64_t>(lds, (c + 2) * sepw);
+    }
+    pl.s_col_begin.assign((size_t)(lds / 64), 0);
+    for (int64_t q = 0; q < lds / 64; ++q) {
+        int64_t c = (64 * q) / sepw;
+        pl.s_col_begin[(size_t)q] = std::max<int64_t>(c - 1, 0) * sepw;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    pl.P = P;
+    return SRK_OK;
+}
+
 // Skyline of the RCS from the covisibility (min_cv[j] = smallest frame index sharing a landmark with frame j).
 // All quantities are aligned to the solver's blocking: env_col multiples of 256, row_end multiples of 128.
 static int build_envelope(srk_ba* h)
@@ -342,7 +447,7 @@ static int build_envelope(srk_ba* h)
     HIPCHK(h, hipMemcpyAsync(h->env_off.p, h->env_off_h.data(), (size_t)(8 * (nt + 1)), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->S.p, 0, (size_t)(8 * d.ld * d.ld), h->stream)); // everything outside the skyline stays 0
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return SRK_OK;
+    return build_chunk_plan(h);
 }
 
 extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
@@ -688,7 +793,7 @@ static int phase_solve(srk_ba* h, bool profile)
     hipStream_t s = h->stream;
     HIPCHK(h, hipMemsetAsync(h->info.p, 0, 4, s));
     hipEvent_t* evs = nullptr;
-    if (profile) {
+    if (profile && h->plan.P < 2) { // per-panel event pairs exist on the single-chain path only
         size_t need = (size_t)(2 * (d.ld / SRK_CHOL_NB));
         while (h->chol_ev.size() < need) {
             hipEvent_t e;
@@ -698,8 +803,12 @@ static int phase_solve(srk_ba* h, bool profile)
         evs = h->chol_ev.data();
     }
     double* wy = P<double>(h->wy);
-    srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info),
-                   h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->dinv), evs);
+    if (h->plan.P >= 2)
+        srk_chol_solve_chunked(s, h->plan, d.ld, P<double>(h->S), P<double>(h->rhs), P<double>(h->dc),
+                               P<int64_t>(h->env_col), P<int>(h->info));
+    else
+        srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info),
+                       h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->dinv), evs);
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
@@ -769,6 +878,7 @@ int srk_ba_phase_solve(srk_ba* h)
     int info = 0;
     rc = read_info(h, &info);
     if (rc != SRK_OK) return rc;
+    if (info && getenv("SRK_DEBUG")) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution)\n", info);
     return info ? 1 : 0;
 }
 int srk_ba_phase_backsub(srk_ba* h, double c)
@@ -900,7 +1010,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->ms_apply += ev_ms(5, 6);
             rep->ms_error += ev_ms(6, 7);
             rep->schur_launches += 2;
-            if (h->profile_syrk) {
+            if (h->profile_syrk && h->plan.P < 2) {
                 int64_t nblk = d.ld / SRK_CHOL_NB;
                 for (int64_t kb = 0; kb < nblk; ++kb) {
                     float ms = 0;
@@ -1151,9 +1261,12 @@ int srk_ba_set_rcs_mode(srk_ba* h, int use_envelope)
 {
     if (!h) return SRK_E_ARGS;
     h->use_envelope = use_envelope != 0;
+    h->use_chunks = use_envelope != 1; // 0 dense, 1 skyline in one chain, 2 (default) skyline cut into chunks
     if (h->have_scene) return build_envelope(h);
     return SRK_OK;
 }
+
+int srk_ba_rcs_chunks(srk_ba* h) { return (h && h->have_scene) ? h->plan.P : 0; }
 
 // fraction of the lower triangle inside the skyline (1.0 = dense)
 double srk_ba_rcs_fill(srk_ba* h)

@@ -147,8 +147,8 @@ __device__ long long g_panel_stamps[16];
 #endif
 #define PANEL_ROWS 63 // matrix rows per workgroup; the 64th quad carries the right-hand side as one more row
 __global__ __launch_bounds__(256) void k_panel(double* __restrict__ A, int64_t ld, int64_t d, int64_t row_end,
-                                               double* __restrict__ w, double* __restrict__ y,
-                                               int* __restrict__ info)
+                                               int64_t r2_begin, int64_t r2_end, double* __restrict__ w,
+                                               double* __restrict__ y, int* __restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
     __shared__ double sCol[2 * NB];
@@ -193,8 +193,13 @@ __global__ __launch_bounds__(256) void k_panel(double* __restrict__ A, int64_t l
     // substitution y_d = L_dd^-1 w_d, at no extra latency.
     const int q = threadIdx.x & 3, qd = threadIdx.x >> 2;
     const bool is_rhs = qd == PANEL_ROWS;
-    int64_t r = k0 + NB + (int64_t)blockIdx.x * PANEL_ROWS + qd;
-    const bool live = !is_rhs && r < row_end;
+    // rows below the diagonal tile inside the skyline [.., row_end) first, then the border rows [r2_begin, r2_end)
+    // (the separator rows of a chunked factorisation; empty otherwise)
+    int64_t rows1 = row_end - (k0 + NB);
+    if (rows1 < 0) rows1 = 0;
+    const int64_t ridx = (int64_t)blockIdx.x * PANEL_ROWS + qd;
+    const int64_t r = ridx < rows1 ? k0 + NB + ridx : r2_begin + (ridx - rows1);
+    const bool live = !is_rhs && ridx < rows1 + (r2_end - r2_begin);
     double* row = is_rhs ? (w + k0) : (A + (live ? r : k0) * ld + k0); // dead rows read the diagonal tile (harmless)
     double a[16];
 #pragma unroll
@@ -267,14 +272,18 @@ extern "C" void srk_dbg_panel_stamps(long long* out) { hipMemcpyFromSymbol(out, 
 // ---------------------------------------------------------------- 64-deep update inside the outer panel (MFMA)
 // A[rt, ct] -= L[rt, d] L[ct, d]^T for row tiles rt > d (rows < row_end) and column tiles d < ct <= c_hi, ct <= rt.
 // grid = (row tiles, column tiles).  4 waves, each a 32x32 quadrant = 2x2 accumulator tiles, K = 64.
-__global__ __launch_bounds__(256) void k_upd64(double* __restrict__ A, int64_t ld, int64_t d, int64_t c_hi)
+__global__ __launch_bounds__(256) void k_upd64(double* __restrict__ A, int64_t ld, int64_t d, int64_t c_hi,
+                                               int64_t tiles1, int64_t r2_begin)
 {
     __shared__ double sA[NB][LDSP];
     __shared__ double sB[NB][LDSP];
+    // row tiles: `tiles1` tiles right below the diagonal tile, then the border tiles starting at r2_begin
+    const bool in1 = (int64_t)blockIdx.x < tiles1;
     int64_t rt = d + 1 + blockIdx.x;
     int64_t ct = d + 1 + blockIdx.y;
-    if (ct > c_hi || ct > rt) return;
-    int64_t k0 = d * NB, r0 = rt * NB, c0 = ct * NB;
+    if (ct > c_hi || (in1 && ct > rt)) return;
+    int64_t k0 = d * NB, c0 = ct * NB;
+    int64_t r0 = in1 ? rt * NB : r2_begin + ((int64_t)blockIdx.x - tiles1) * NB;
     {
         int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
         const double* pa = A + (r0 + row) * ld + k0 + seg;
@@ -326,7 +335,8 @@ __global__ __launch_bounds__(256) void k_upd64(double* __restrict__ A, int64_t l
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
 // C[ti, tj] -= P[ti] P[tj]^T over the 128x128 tile pairs ti >= tj of rows/cols [c_first, row_end), P = the 256
 // panel columns starting at k0.  One workgroup per tile pair (linear index -> triangular pair).
-__global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first)
+__global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first,
+                                                  int64_t T1, int64_t r2_begin)
 {
     __shared__ double sA[2][TL][KCP];
     __shared__ double sB[2][TL][KCP];
@@ -335,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_
     while ((int64_t)(ti + 1) * (ti + 2) / 2 <= p) ++ti;
     while ((int64_t)ti * (ti + 1) / 2 > p) --ti;
     int tj = (int)(p - (int64_t)ti * (ti + 1) / 2);
-    const int64_t r0 = c_first + (int64_t)ti * TL, c0 = c_first + (int64_t)tj * TL;
+    // tile i of the list: T1 tiles from c_first (inside the skyline), then the border tiles from r2_begin
+    const int64_t r0 = ti < T1 ? c_first + (int64_t)ti * TL : r2_begin + ((int64_t)ti - T1) * TL;
+    const int64_t c0 = tj < T1 ? c_first + (int64_t)tj * TL : r2_begin + ((int64_t)tj - T1) * TL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
@@ -419,7 +431,8 @@ __global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_
 // ---------------------------------------------------------------- trailing update, small-skyline variant
 // Same contraction as k_trail on 64x64 tiles (4x the workgroups, a quarter of the serial work each): when only a few
 // 128-tiles are inside the skyline the update is latency-bound and the grid, not the tile shape, sets its time.
-__global__ __launch_bounds__(256) void k_trail64(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first)
+__global__ __launch_bounds__(256) void k_trail64(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first,
+                                                 int64_t T1, int64_t r2_begin)
 {
     __shared__ double sA[NB][LDSP];
     __shared__ double sB[NB][LDSP];
@@ -428,7 +441,8 @@ __global__ __launch_bounds__(256) void k_trail64(double* __restrict__ A, int64_t
     while ((int64_t)(ti + 1) * (ti + 2) / 2 <= p) ++ti;
     while ((int64_t)ti * (ti + 1) / 2 > p) --ti;
     int tj = (int)(p - (int64_t)ti * (ti + 1) / 2);
-    const int64_t r0 = c_first + (int64_t)ti * NB, c0 = c_first + (int64_t)tj * NB;
+    const int64_t r0 = ti < T1 ? c_first + (int64_t)ti * NB : r2_begin + ((int64_t)ti - T1) * NB;
+    const int64_t c0 = tj < T1 ? c_first + (int64_t)tj * NB : r2_begin + ((int64_t)tj - T1) * NB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
@@ -558,45 +572,60 @@ __global__ __launch_bounds__(256) void k_check_finite(int64_t n, const double* _
     if (i < n && !isfinite(x[i])) atomicOr(info, 4);
 }
 
-// w: right-hand side (destroyed).  y: scratch (forward solution).  x: solution.
-// row_end[K] (host, one per outer panel, multiple of 128, > 256 (K+1) or == ld): rows >= row_end[K] have no
-// non-zero in the panel's columns and are skipped; NULL = dense.  col_begin[d64] (host, per 64-tile, may be NULL):
-// first column with a non-zero in tile row d64.  dinv: scratch, (ld / 64) * 64 * 64 doubles (inverses of the
-// diagonal tiles).  ev_pairs: optional 2 events per outer panel around the trailing update.
-void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
-                    const int64_t* row_end, const int64_t* col_begin, double* dinv, hipEvent_t* ev_pairs)
+// ---------------------------------------------------------------- host drivers
+// chol_factor: eliminate the first `ncols` columns (multiple of 256) of A.  Rows taking part in outer panel K are the
+// skyline rows [256 K, row_end[K]) (clipped to ncols) plus the border rows [r2_begin, r2_end) (multiples of 128;
+// empty when r2_begin == r2_end).  The forward substitution of w rides along (k_panel); y receives L^-1 w for the
+// eliminated columns, the border part of w receives its Schur-complement update.
+static void chol_factor(hipStream_t s, int64_t ld, double* A, int64_t ncols, double* w, double* y, int* d_info,
+                        const int64_t* row_end, int64_t r2_begin, int64_t r2_end, hipEvent_t* ev_pairs)
 {
-    const int64_t nout = ld / NBO;
+    const int64_t nout = ncols / NBO;
+    const int64_t rows2 = r2_end - r2_begin;
     for (int64_t K = 0; K < nout; ++K) {
         const int64_t k0 = K * NBO;
-        int64_t rend = row_end ? row_end[K] : ld;
+        int64_t rend = row_end ? row_end[K] : ncols;
         if (rend < k0 + NBO) rend = k0 + NBO;
-        if (rend > ld) rend = ld;
+        if (rend > ncols) rend = ncols;
         for (int jsub = 0; jsub < NBO / NB; ++jsub) {
             int64_t d = K * (NBO / NB) + jsub;
-            int64_t rows = rend - (d + 1) * NB;
+            int64_t rows1 = rend - (d + 1) * NB;
+            if (rows1 < 0) rows1 = 0;
+            int64_t rows = rows1 + rows2;
             int64_t blocks = rows > 0 ? (rows + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-            hipLaunchKernelGGL(k_panel, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, d, rend, w, y, d_info);
+            hipLaunchKernelGGL(k_panel, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, d, rend, r2_begin, r2_end, w, y,
+                               d_info);
             int64_t c_hi = K * (NBO / NB) + (NBO / NB - 1);
             if (jsub < NBO / NB - 1 && rows > 0) {
-                int64_t rtiles = rows / NB;
+                int64_t tiles1 = rows1 / NB, tiles2 = rows2 / NB;
                 int64_t ctiles = c_hi - d;
-                hipLaunchKernelGGL(k_upd64, dim3((unsigned)rtiles, (unsigned)ctiles), dim3(256), 0, s, A, ld, d, c_hi);
+                hipLaunchKernelGGL(k_upd64, dim3((unsigned)(tiles1 + tiles2), (unsigned)ctiles), dim3(256), 0, s, A, ld,
+                                   d, c_hi, tiles1, r2_begin);
             }
         }
         int64_t c_first = k0 + NBO;
-        int64_t T = (rend - c_first) / TL;
+        int64_t T1 = (rend - c_first) / TL;
+        if (T1 < 0) T1 = 0;
+        int64_t T = T1 + rows2 / TL;
         if (ev_pairs) hipEventRecord(ev_pairs[2 * K], s);
         if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
             int64_t T64 = 2 * T;
-            hipLaunchKernelGGL(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2)), dim3(256), 0, s, A, ld, k0, c_first);
+            hipLaunchKernelGGL(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2)), dim3(256), 0, s, A, ld, k0, c_first,
+                               2 * T1, r2_begin);
         } else if (T > 0) {
             int64_t pairs = T * (T + 1) / 2;
-            hipLaunchKernelGGL(k_trail, dim3((unsigned)pairs), dim3(256), 0, s, A, ld, k0, c_first);
+            hipLaunchKernelGGL(k_trail, dim3((unsigned)pairs), dim3(256), 0, s, A, ld, k0, c_first, T1, r2_begin);
         }
         if (ev_pairs) hipEventRecord(ev_pairs[2 * K + 1], s);
     }
-    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(ld / NB)), dim3(64), 0, s, A, ld, dinv);
+}
+
+// chol_bwd: x = L^-T y over the first `ncols` columns (the border part, if any, has been folded into y already)
+static void chol_bwd(hipStream_t s, int64_t ld, const double* A, int64_t ncols, const int64_t* col_begin, double* dinv,
+                     double* y, double* x)
+{
+    const int64_t nout = ncols / NBO;
+    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(ncols / NB)), dim3(64), 0, s, A, ld, dinv);
     for (int64_t K = nout - 1; K >= 0; --K) {
         int64_t cb = col_begin ? col_begin[K * (NBO / NB)] : 0;
         for (int q = 1; q < NBO / NB; ++q)
@@ -606,5 +635,168 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
         int64_t blocks = cols > 0 ? (cols + 255) / 256 : 1;
         hipLaunchKernelGGL(k_bwd256, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, K, cb, dinv, y, x);
     }
+}
+
+// w: right-hand side (destroyed).  y: scratch (forward solution).  x: solution.
+// row_end[K] (host, one per outer panel, multiple of 128): rows >= row_end[K] have no non-zero in the panel's
+// columns and are skipped; NULL = dense.  col_begin[d64] (host, per 64-tile, may be NULL): first column with a
+// non-zero in tile row d64.  dinv: scratch, (ld / 64) * 64 * 64 doubles (inverses of the diagonal tiles).
+// ev_pairs: optional 2 events per outer panel around the trailing update.
+void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
+                    const int64_t* row_end, const int64_t* col_begin, double* dinv, hipEvent_t* ev_pairs)
+{
+    chol_factor(s, ld, A, ld, w, y, d_info, row_end, ld, ld, ev_pairs);
+    chol_bwd(s, ld, A, ld, col_begin, dinv, y, x);
+    hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
+}
+
+// ================================================================ chunked (bordered block-diagonal) solve
+// A banded reduced camera system is a chain of n dependent pivots.  Cut it into P chunks separated by P-1 separators
+// of `sepw` variables (sepw >= the bandwidth, so chunks do not touch each other): every chunk
+//     [ A_c   B_c^T ]      A_c : the chunk (skyline),  B_c : its couplings to the separator above and below
+//     [ B_c    0    ]
+// is factorised INDEPENDENTLY on its own stream (the separator rows ride along as border rows of every panel and end
+// up holding Y_c = B_c L_c^-T, the border block holds -Y_c Y_c^T); the small separator system
+// C - sum_c Y_c Y_c^T is solved next, and the chunks are back-substituted concurrently again.  Exact arithmetic is
+// the same as one Cholesky of a re-ordered matrix; the dependency chain is n / P + sepw (P - 1) pivots instead of n.
+
+// one workgroup per local row of the chunk matrix
+__global__ __launch_bounds__(256) void k_chunk_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
+                                                      const int64_t* __restrict__ env_col, int64_t a, int64_t nc,
+                                                      int64_t sepw, int has_top, int has_bot, double* __restrict__ Ac,
+                                                      int64_t ldc, double* __restrict__ wc)
+{
+    const int64_t i = blockIdx.x;
+    double* dst = Ac + i * ldc;
+    if (i < nc) {
+        const int64_t g = a + i;
+        int64_t c0 = env_col[g / 128] - a;
+        if (c0 < 0) c0 = 0;
+        const int64_t c1 = 128 * (i / 128 + 1); // end of this row's skyline segment (tile aligned, <= nc)
+        const double* src = S + g * ld + a;
+        for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) dst[j] = src[j];
+        if (threadIdx.x == 0) wc[i] = rhs[g];
+        return;
+    }
+    const int64_t u2 = i - nc; // border row: [0, sepw) separator above, [sepw, 2 sepw) separator below
+    if (u2 < sepw) {
+        const int64_t g = a - sepw + u2; // column g of the rows below it (the coupling lives in S[a + j][g])
+        const int64_t jn = nc < 2 * sepw ? nc : 2 * sepw;
+        for (int64_t j = threadIdx.x; j < ldc; j += 256)
+            dst[j] = (has_top && j < jn) ? S[(a + j) * ld + g] : 0.0;
+    } else {
+        const int64_t g = a + nc + (u2 - sepw);
+        const int64_t j0 = nc > 2 * sepw ? nc - 2 * sepw : 0;
+        for (int64_t j = threadIdx.x; j < ldc; j += 256)
+            dst[j] = (has_bot && j >= j0 && j < nc) ? S[g * ld + a + j] : 0.0;
+    }
+    if (threadIdx.x == 0) wc[i] = 0.0;
+}
+
+// separator system: Cs (lds x lds) block diagonal part from S, ws from rhs
+__global__ __launch_bounds__(256) void k_sep_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
+                                                    const int64_t* __restrict__ sep_start, int64_t sepw,
+                                                    double* __restrict__ Cs, int64_t lds, double* __restrict__ ws)
+{
+    const int64_t i = blockIdx.x; // row of Cs
+    const int64_t c = i / sepw, u = i - c * sepw;
+    const int64_t g = sep_start[c] + u;
+    double* dst = Cs + i * lds;
+    for (int64_t j = threadIdx.x; j < lds; j += 256) {
+        int64_t cj = j / sepw, v = j - cj * sepw;
+        dst[j] = (cj == c && v <= u) ? S[g * ld + sep_start[c] + v] : 0.0;
+    }
+    if (threadIdx.x == 0) ws[i] = rhs[g];
+}
+
+// add a chunk's border block (-Y Y^T) and border rhs into the separator system (one launch per chunk, in order)
+__global__ __launch_bounds__(256) void k_sep_reduce(const double* __restrict__ Ac, int64_t ldc, const double* __restrict__ wc,
+                                                    int64_t nc, int64_t sepw, int64_t top_sep /* -1 = none */,
+                                                    int64_t bot_sep /* -1 = none */, double* __restrict__ Cs,
+                                                    int64_t lds, double* __restrict__ ws)
+{
+    const int64_t u2 = blockIdx.x; // border row 0 .. 2 sepw - 1
+    const int64_t su = u2 < sepw ? top_sep : bot_sep;
+    if (su < 0) return;
+    const int64_t ru = su * sepw + (u2 < sepw ? u2 : u2 - sepw);
+    const double* src = Ac + (nc + u2) * ldc + nc;
+    for (int64_t v2 = threadIdx.x; v2 <= u2; v2 += 256) {
+        const int64_t sv = v2 < sepw ? top_sep : bot_sep;
+        if (sv < 0) continue;
+        const int64_t cv = sv * sepw + (v2 < sepw ? v2 : v2 - sepw);
+        Cs[ru * lds + cv] += src[v2];
+    }
+    if (threadIdx.x == 0) ws[ru] += wc[nc + u2];
+}
+
+// border part of the chunk's solution = the separator solution; then fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i]
+__global__ __launch_bounds__(256) void k_bwd_border(const double* __restrict__ Ac, int64_t ldc, int64_t nc, int64_t sepw,
+                                                    int64_t top_sep, int64_t bot_sep, const double* __restrict__ xs,
+                                                    double* __restrict__ yc)
+{
+    __shared__ double sx[1024];
+    for (int64_t u2 = threadIdx.x; u2 < 2 * sepw; u2 += 256) {
+        const int64_t su = u2 < sepw ? top_sep : bot_sep;
+        sx[u2] = su < 0 ? 0.0 : xs[su * sepw + (u2 < sepw ? u2 : u2 - sepw)];
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nc) return;
+    const double* col = Ac + nc * ldc + j;
+    double acc = 0;
+#pragma unroll 8
+    for (int64_t u2 = 0; u2 < 2 * sepw; ++u2) acc += col[u2 * ldc] * sx[u2];
+    yc[j] -= acc;
+}
+
+__global__ void k_scatter(int64_t n, const double* __restrict__ src, double* __restrict__ dst)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
+                            double* x, const int64_t* d_env_col, int* d_info)
+{
+    const int P = pl.P;
+    const int64_t sepw = pl.sepw;
+    // fork: chunk streams wait for the assembled system
+    hipEventRecord(pl.ev_fork, s);
+    for (int c = 0; c < P; ++c) {
+        hipStream_t cs = pl.streams[c];
+        hipStreamWaitEvent(cs, pl.ev_fork, 0);
+        const int64_t nc = pl.n[c], ldc = pl.ldc[c];
+        hipLaunchKernelGGL(k_chunk_gather, dim3((unsigned)ldc), dim3(256), 0, cs, S, ld, rhs, d_env_col, pl.a[c], nc, sepw,
+                           c > 0, c < P - 1, pl.Ac[c], ldc, pl.wc[c]);
+        chol_factor(cs, ldc, pl.Ac[c], nc, pl.wc[c], pl.yc[c], d_info, pl.row_end[c].data(), nc, ldc, nullptr);
+        hipEventRecord(pl.ev_join[c], cs);
+    }
+    // separator system on the main stream (its gather overlaps the chunk factorisations)
+    const int64_t lds = pl.lds;
+    hipLaunchKernelGGL(k_sep_gather, dim3((unsigned)lds), dim3(256), 0, s, S, ld, rhs, pl.d_sep_start, sepw, pl.Cs, lds,
+                       pl.ws);
+    for (int c = 0; c < P; ++c) {
+        hipStreamWaitEvent(s, pl.ev_join[c], 0);
+        hipLaunchKernelGGL(k_sep_reduce, dim3((unsigned)(2 * sepw)), dim3(256), 0, s, pl.Ac[c], pl.ldc[c], pl.wc[c],
+                           pl.n[c], sepw, (int64_t)(c > 0 ? c - 1 : -1), (int64_t)(c < P - 1 ? c : -1), pl.Cs, lds, pl.ws);
+    }
+    chol_factor(s, lds, pl.Cs, lds, pl.ws, pl.ys, d_info, pl.s_row_end.data(), lds, lds, nullptr);
+    chol_bwd(s, lds, pl.Cs, lds, pl.s_col_begin.data(), pl.dinvs, pl.ys, pl.xs);
+    for (int c = 0; c + 1 < P; ++c) // separator variables of the global solution
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((sepw + 255) / 256)), dim3(256), 0, s, sepw, pl.xs + c * sepw,
+                           x + pl.a[c] + pl.n[c]);
+    hipEventRecord(pl.ev_fork2, s);
+    // back-substitution of the chunks, concurrently again
+    for (int c = 0; c < P; ++c) {
+        hipStream_t cs = pl.streams[c];
+        hipStreamWaitEvent(cs, pl.ev_fork2, 0);
+        const int64_t nc = pl.n[c], ldc = pl.ldc[c];
+        hipLaunchKernelGGL(k_bwd_border, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, cs, pl.Ac[c], ldc, nc, sepw,
+                           (int64_t)(c > 0 ? c - 1 : -1), (int64_t)(c < P - 1 ? c : -1), pl.xs, pl.yc[c]);
+        chol_bwd(cs, ldc, pl.Ac[c], nc, pl.col_begin[c].data(), pl.dinvc[c], pl.yc[c], pl.xc[c]);
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, cs, nc, pl.xc[c], x + pl.a[c]);
+        hipEventRecord(pl.ev_join[c], cs);
+    }
+    for (int c = 0; c < P; ++c) hipStreamWaitEvent(s, pl.ev_join[c], 0);
     hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }

@@ -80,3 +80,28 @@ void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, cons
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
                     const int64_t* row_end, const int64_t* col_begin, double* dinv /* (ld / 64) * 4096 doubles */,
                     hipEvent_t* ev_pairs /* 2 * (ld / SRK_CHOL_NB) events or NULL */);
+
+// ---- chunked (bordered block-diagonal) solve of a banded reduced camera system (srk_chol.hip) ----
+#include <vector>
+#define SRK_MAX_CHUNKS 8
+struct SrkChunkPlan {
+    int P = 0;                       // number of chunks; < 2 = not used
+    int64_t sepw = 256;              // separator width (variables), >= bandwidth
+    int64_t a[SRK_MAX_CHUNKS]{};     // first global variable of chunk c
+    int64_t n[SRK_MAX_CHUNKS]{};     // interior size of chunk c (multiple of 256)
+    int64_t ldc[SRK_MAX_CHUNKS]{};   // n + 2 sepw
+    double* Ac[SRK_MAX_CHUNKS]{};    // chunk matrices (ldc x ldc)
+    double* wc[SRK_MAX_CHUNKS]{};
+    double* yc[SRK_MAX_CHUNKS]{};
+    double* xc[SRK_MAX_CHUNKS]{};
+    double* dinvc[SRK_MAX_CHUNKS]{};
+    std::vector<int64_t> row_end[SRK_MAX_CHUNKS], col_begin[SRK_MAX_CHUNKS]; // local skylines
+    int64_t lds = 0;                 // separator system size = sepw (P - 1)
+    double *Cs = nullptr, *ws = nullptr, *ys = nullptr, *xs = nullptr, *dinvs = nullptr;
+    std::vector<int64_t> s_row_end, s_col_begin;
+    int64_t* d_sep_start = nullptr;  // device: first global variable of separator c
+    hipStream_t streams[SRK_MAX_CHUNKS]{};
+    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[SRK_MAX_CHUNKS]{};
+};
+void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
+                            double* x, const int64_t* d_env_col, int* d_info);

@@ -395,3 +395,55 @@ def test_allreduce_hook_with_device_pointers(orc, gpu):
         h.close()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ chunked (bordered block-diagonal) solve
+
+@pytest.mark.parametrize("n_frames,window", [(330, 8), (500, 12), (500, 30)])
+def test_chunked_solve_equals_single_chain(gpu, n_frames, window):
+    """Banded reduced camera system cut into independent chunks + separator system (srk_chol_solve_chunked) against
+    the single-chain skyline Cholesky and against numpy on the downloaded system.  window 30 needs 512-wide
+    separators."""
+    spec = sa.SceneSpec(n_frames=n_frames, grid_nx=60, grid_ny=40, vis_window=window)  # every frame well observed
+    sc = sa.generate_scene(spec)
+    c = 1e-3
+    sols = {}
+    for mode in (2, 1):
+        gpu.set_rcs_mode(mode)
+        assert gpu.upload(spec.f0, sc)
+        if mode == 2:
+            assert gpu.rcs_chunks() >= 2
+        else:
+            assert gpu.rcs_chunks() == 0
+        gpu.phase_derivatives()
+        gpu.phase_schur(c)
+        if mode == 2:
+            S = gpu.buffer(B.BUF_RCS).reshape(10 * n_frames, 10 * n_frames)
+            rhs = gpu.buffer(B.BUF_RCS_RHS)
+        assert gpu.phase_solve()
+        gpu.phase_backsub(c)
+        sols[mode] = gpu.buffer(B.BUF_CORRECTIONS)
+    gpu.set_rcs_mode(2)
+    x = np.linalg.solve(S, rhs)
+    for _ in range(3):
+        x = x + np.linalg.solve(S, rhs - S @ x)
+    dc2 = sols[2][3 * sc.N:]
+    assert rel_err(dc2, x) < 1e-9
+    assert rel_err(sols[2], sols[1]) < 1e-9
+    assert np.all(dc2[4:10] == 0) and dc2[15] == 0
+
+
+def test_chunked_end_to_end_matches_single_chain(gpu):
+    spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
+    sc = sa.generate_scene(spec)
+    res = {}
+    for mode in (2, 1):
+        gpu.set_rcs_mode(mode)
+        s2 = sc.copy()
+        gpu.ComputeInplace(spec.f0, s2, None, 4)
+        res[mode] = (gpu.report.iterations, gpu.report.attempts, gpu.report.err_final, s2)
+    gpu.set_rcs_mode(2)
+    assert res[1][:2] == res[2][:2]
+    assert res[2][2] == pytest.approx(res[1][2], rel=1e-8)
+    assert np.abs(res[2][3].points - res[1][3].points).max() < 1e-8
+    assert np.abs(res[2][3].cam_T - res[1][3].cam_T).max() < 1e-8
