@@ -57,12 +57,10 @@ struct srk_ba {
     DevBuf env_col, env_off, packed, dinv;
     int64_t env_packed = 0;
     bool use_envelope = true;
-    // chunked solve of a banded system (srk_chol.hip): plan + its buffers + the chunk streams
+    // chunked solve of a banded system (srk_chol.hip): plan + its buffers
     bool use_chunks = true;
     SrkChunkPlan plan;
     std::vector<DevBuf> plan_bufs;
-    hipStream_t chunk_streams[SRK_MAX_CHUNKS]{};
-    hipEvent_t chunk_events[SRK_MAX_CHUNKS + 2]{};
     int cur = 0; // index of the current scene buffers; 1-cur = trial
 
     // multi-GPU exchange
@@ -141,16 +139,6 @@ srk_ba* srk_ba_create(int device_id)
             delete h;
             return nullptr;
         }
-    for (auto& cs : h->chunk_streams)
-        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) {
-            delete h;
-            return nullptr;
-        }
-    for (auto& e : h->chunk_events)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-            delete h;
-            return nullptr;
-        }
     return h;
 }
 
@@ -166,10 +154,6 @@ void srk_ba_destroy(srk_ba* h)
                       &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv };
     for (DevBuf* b : all) dev_free(*b);
     for (DevBuf& b : h->plan_bufs) dev_free(b);
-    for (auto& cs : h->chunk_streams)
-        if (cs) hipStreamDestroy(cs);
-    for (auto& e : h->chunk_events)
-        if (e) hipEventDestroy(e);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : h->chol_ev) hipEventDestroy(e);
@@ -338,8 +322,15 @@ static int build_chunk_plan(srk_ba* h)
     for (int32_t j = 0; j < d.M; ++j) maxdist = std::max<int64_t>(maxdist, 10 * (int64_t)(j - h->min_cv[(size_t)j]) + 9);
     int64_t sepw = maxdist <= 256 ? 256 : (maxdist <= 512 ? 512 : 0);
     if (sepw == 0) return SRK_OK;
-    int P = (int)std::min<int64_t>(SRK_MAX_CHUNKS, d.ld / 1536);
-    while (P >= 2 && (d.ld - sepw * (P - 1)) / P < 2 * sepw) --P; // chunks at least two separators wide
+    // dependency chain of the chunked solve: interior / P pivots per chunk, then sepw (P - 1) for the separator system
+    int P = 0;
+    int64_t best = d.ld;
+    for (int p = 2; p <= SRK_MAX_CHUNKS; ++p) {
+        const int64_t inner = (d.ld - sepw * (p - 1)) / p;
+        if (inner < 2 * sepw) break; // chunks at least two separators wide
+        const int64_t chain = (inner + SRK_CHOL_NB - 1) / SRK_CHOL_NB * SRK_CHOL_NB + sepw * (p - 1);
+        if (chain < best) best = chain, P = p;
+    }
     if (P < 2) return SRK_OK;
     const int64_t interior = d.ld - sepw * (P - 1);
     const int64_t blocks = interior / SRK_CHOL_NB; // interior is a multiple of 256 (ld and sepw are)
@@ -378,11 +369,7 @@ static int build_chunk_plan(srk_ba* h)
         pl.col_begin[c].assign((size_t)(nc / 64), 0);
         for (int64_t q = 0; q < nc / 64; ++q)
             pl.col_begin[c][(size_t)q] = std::max<int64_t>(h->col_begin_h[(size_t)(pl.a[c] / 64 + q)] - pl.a[c], 0);
-        pl.streams[c] = h->chunk_streams[c];
-        pl.ev_join[c] = h->chunk_events[c];
     }
-    pl.ev_fork = h->chunk_events[SRK_MAX_CHUNKS];
-    pl.ev_fork2 = h->chunk_events[SRK_MAX_CHUNKS + 1];
     const int64_t lds = pl.lds;
     pl.Cs = (double*)alloc((size_t)(8 * lds * lds), true);
     pl.ws = (double*)alloc((size_t)(8 * lds), true);

@@ -135,6 +135,22 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sCol /*[2]
     return !(dmin > 0.0) || (dchk != 0.0);
 }
 
+// ---------------------------------------------------------------- batched launches
+// Every factorisation kernel works on a BATCH of independent matrices (blockIdx.z = item): the chunks of a chunked
+// solve advance in lock step through the same launches, so the launch count is that of ONE chunk and no extra streams
+// are needed.  A plain solve is a batch of one.  The descriptors travel by value in the kernel arguments.
+struct CholItem {
+    double* A;   // matrix (ld x ld, row-major, lower part authoritative)
+    double* w;   // running right-hand side
+    double* y;   // forward solution
+    double* x;   // solution
+    double* dinv; // inverses of the diagonal 64-tiles
+    int64_t ld, ncols, r2_begin, r2_end; // eliminate columns [0, ncols); border rows [r2_begin, r2_end) ride along
+};
+struct CholBatch { CholItem it[SRK_MAX_CHUNKS]; };
+struct CholStep { int64_t v[SRK_MAX_CHUNKS]; }; // one per-launch value per item; < 0 = item takes no part
+struct CholHostItem { const int64_t* row_end; const int64_t* col_begin; }; // host skylines of an item (may be NULL)
+
 // ---------------------------------------------------------------- inner panel: potrf + trsm + forward substitution
 // d = index of the 64-wide diagonal tile.  Rows (d+1)*64 .. row_end-1 of columns [64 d, 64 d + 64) become L.
 // w is the running right-hand side: y_d = L_dd^-1 w_d is published to y, and w_r -= L[r, d-cols] . y_d for the
@@ -146,10 +162,21 @@ __device__ long long g_panel_stamps[16];
 #define STAMP(k)
 #endif
 #define PANEL_ROWS 63 // matrix rows per workgroup; the 64th quad carries the right-hand side as one more row
-__global__ __launch_bounds__(256) void k_panel(double* __restrict__ A, int64_t ld, int64_t d, int64_t row_end,
-                                               int64_t r2_begin, int64_t r2_end, double* __restrict__ w,
-                                               double* __restrict__ y, int* __restrict__ info)
+__global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep rend, int64_t d, int* __restrict__ info)
 {
+    const int64_t row_end = rend.v[blockIdx.z];
+    if (row_end < 0) return;
+    double* __restrict__ A = B.it[blockIdx.z].A;
+    double* __restrict__ w = B.it[blockIdx.z].w;
+    double* __restrict__ y = B.it[blockIdx.z].y;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin, r2_end = B.it[blockIdx.z].r2_end;
+    {
+        int64_t rows = row_end - (d + 1) * NB;
+        if (rows < 0) rows = 0;
+        rows += r2_end - r2_begin;
+        const int64_t blocks = rows > 0 ? (rows + PANEL_ROWS - 1) / PANEL_ROWS : 1;
+        if ((int64_t)blockIdx.x >= blocks) return; // the grid is sized for the largest item of the batch
+    }
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
     __shared__ double sCol[2 * NB];
     __shared__ double sDiag[NB];
@@ -272,11 +299,16 @@ extern "C" void srk_dbg_panel_stamps(long long* out) { hipMemcpyFromSymbol(out, 
 // ---------------------------------------------------------------- 64-deep update inside the outer panel (MFMA)
 // A[rt, ct] -= L[rt, d] L[ct, d]^T for row tiles rt > d (rows < row_end) and column tiles d < ct <= c_hi, ct <= rt.
 // grid = (row tiles, column tiles).  4 waves, each a 32x32 quadrant = 2x2 accumulator tiles, K = 64.
-__global__ __launch_bounds__(256) void k_upd64(double* __restrict__ A, int64_t ld, int64_t d, int64_t c_hi,
-                                               int64_t tiles1, int64_t r2_begin)
+__global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep rend, int64_t d, int64_t c_hi)
 {
     __shared__ double sA[NB][LDSP];
     __shared__ double sB[NB][LDSP];
+    if (rend.v[blockIdx.z] < 0) return;
+    double* __restrict__ A = B.it[blockIdx.z].A;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin;
+    int64_t tiles1 = (rend.v[blockIdx.z] - (d + 1) * NB) / NB;
+    if (tiles1 < 0) tiles1 = 0;
+    if ((int64_t)blockIdx.x >= tiles1 + (B.it[blockIdx.z].r2_end - r2_begin) / NB) return;
     // row tiles: `tiles1` tiles right below the diagonal tile, then the border tiles starting at r2_begin
     const bool in1 = (int64_t)blockIdx.x < tiles1;
     int64_t rt = d + 1 + blockIdx.x;
@@ -335,12 +367,20 @@ __global__ __launch_bounds__(256) void k_upd64(double* __restrict__ A, int64_t l
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
 // C[ti, tj] -= P[ti] P[tj]^T over the 128x128 tile pairs ti >= tj of rows/cols [c_first, row_end), P = the 256
 // panel columns starting at k0.  One workgroup per tile pair (linear index -> triangular pair).
-__global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first,
-                                                  int64_t T1, int64_t r2_begin)
+__global__ __launch_bounds__(256, 2) void k_trail(const CholBatch B, const CholStep rend, int64_t k0, int64_t c_first)
 {
     __shared__ double sA[2][TL][KCP];
     __shared__ double sB[2][TL][KCP];
+    if (rend.v[blockIdx.z] < 0) return;
+    double* __restrict__ A = B.it[blockIdx.z].A;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin;
+    int64_t T1 = (rend.v[blockIdx.z] - c_first) / TL;
+    if (T1 < 0) T1 = 0;
     int64_t p = blockIdx.x;
+    {
+        const int64_t T = T1 + (B.it[blockIdx.z].r2_end - r2_begin) / TL;
+        if (p >= T * (T + 1) / 2) return;
+    }
     int ti = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
     while ((int64_t)(ti + 1) * (ti + 2) / 2 <= p) ++ti;
     while ((int64_t)ti * (ti + 1) / 2 > p) --ti;
@@ -431,12 +471,20 @@ __global__ __launch_bounds__(256, 2) void k_trail(double* __restrict__ A, int64_
 // ---------------------------------------------------------------- trailing update, small-skyline variant
 // Same contraction as k_trail on 64x64 tiles (4x the workgroups, a quarter of the serial work each): when only a few
 // 128-tiles are inside the skyline the update is latency-bound and the grid, not the tile shape, sets its time.
-__global__ __launch_bounds__(256) void k_trail64(double* __restrict__ A, int64_t ld, int64_t k0, int64_t c_first,
-                                                 int64_t T1, int64_t r2_begin)
+__global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholStep rend, int64_t k0, int64_t c_first)
 {
     __shared__ double sA[NB][LDSP];
     __shared__ double sB[NB][LDSP];
+    if (rend.v[blockIdx.z] < 0) return;
+    double* __restrict__ A = B.it[blockIdx.z].A;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin;
+    int64_t T1 = (rend.v[blockIdx.z] - c_first) / NB;
+    if (T1 < 0) T1 = 0;
     int64_t p = blockIdx.x;
+    {
+        const int64_t T = T1 + (B.it[blockIdx.z].r2_end - r2_begin) / NB;
+        if (p >= T * (T + 1) / 2) return;
+    }
     int ti = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
     while ((int64_t)(ti + 1) * (ti + 2) / 2 <= p) ++ti;
     while ((int64_t)ti * (ti + 1) / 2 > p) --ti;
@@ -498,11 +546,15 @@ __global__ __launch_bounds__(256) void k_trail64(double* __restrict__ A, int64_t
 // ---------------------------------------------------------------- backward substitution L^T x = y
 // k_dinv: Dinv[d] = L_dd^-1 (lower triangular, 64x64) for every diagonal tile at once -- it turns the 64 dependent
 // steps of each triangular solve into one small matrix-vector product.
-__global__ __launch_bounds__(64) void k_dinv(const double* __restrict__ A, int64_t ld, double* __restrict__ Dinv)
+__global__ __launch_bounds__(64) void k_dinv(const CholBatch B)
 {
     __shared__ double sL[NB][NB + 1];
     __shared__ double sZ[NB][NB + 1];
     const int64_t k0 = (int64_t)blockIdx.x * NB;
+    if (k0 >= B.it[blockIdx.z].ncols) return;
+    const double* __restrict__ A = B.it[blockIdx.z].A;
+    double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
+    const int64_t ld = B.it[blockIdx.z].ld;
     const int t = threadIdx.x;
     for (int e = t; e < NB * NB; e += 64) {
         int i = e >> 6, c = e & 63;
@@ -524,12 +576,21 @@ __global__ __launch_bounds__(64) void k_dinv(const double* __restrict__ A, int64
 // step K (descending, 256 rows): x_K = L_KK^-T y_K by four tile back-substitutions with the explicit tile inverses
 // (every workgroup, redundantly), then y_j -= sum_i L[256 K + i, j] x_K[i] for this workgroup's columns
 // j in [col_begin, 256 K).
-__global__ __launch_bounds__(256) void k_bwd256(const double* __restrict__ A, int64_t ld, int64_t K, int64_t col_begin,
-                                                const double* __restrict__ Dinv, double* __restrict__ y,
-                                                double* __restrict__ x)
+__global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholStep Kst, const CholStep cbeg)
 {
     __shared__ double sv[NBO];
+    const int64_t K = Kst.v[blockIdx.z], col_begin = cbeg.v[blockIdx.z];
+    if (K < 0) return;
     const int64_t k0 = K * NBO;
+    {
+        const int64_t cols = k0 - col_begin;
+        if ((int64_t)blockIdx.x >= (cols > 0 ? (cols + 255) / 256 : 1)) return;
+    }
+    const double* __restrict__ A = B.it[blockIdx.z].A;
+    const double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
+    double* __restrict__ y = B.it[blockIdx.z].y;
+    double* __restrict__ x = B.it[blockIdx.z].x;
+    const int64_t ld = B.it[blockIdx.z].ld;
     const int t = threadIdx.x;
     sv[t] = y[k0 + t];
     __syncthreads();
@@ -573,67 +634,91 @@ __global__ __launch_bounds__(256) void k_check_finite(int64_t n, const double* _
 }
 
 // ---------------------------------------------------------------- host drivers
-// chol_factor: eliminate the first `ncols` columns (multiple of 256) of A.  Rows taking part in outer panel K are the
-// skyline rows [256 K, row_end[K]) (clipped to ncols) plus the border rows [r2_begin, r2_end) (multiples of 128;
-// empty when r2_begin == r2_end).  The forward substitution of w rides along (k_panel); y receives L^-1 w for the
-// eliminated columns, the border part of w receives its Schur-complement update.
-static void chol_factor(hipStream_t s, int64_t ld, double* A, int64_t ncols, double* w, double* y, int* d_info,
-                        const int64_t* row_end, int64_t r2_begin, int64_t r2_end, hipEvent_t* ev_pairs)
+// chol_factor: for every item of the batch, eliminate its first `ncols` columns (multiple of 256).  Rows taking part
+// in outer panel K are the skyline rows [256 K, row_end[K]) (clipped to ncols) plus the border rows
+// [r2_begin, r2_end) (multiples of 128; empty when r2_begin == r2_end).  The forward substitution of w rides along
+// (k_panel); y receives L^-1 w for the eliminated columns, the border part of w its Schur-complement update.
+// Items advance in lock step: launch K serves outer panel K of every item that has one.
+static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, int* d_info, hipEvent_t* ev_pairs)
 {
-    const int64_t nout = ncols / NBO;
-    const int64_t rows2 = r2_end - r2_begin;
+    int64_t nout = 0;
+    for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
     for (int64_t K = 0; K < nout; ++K) {
         const int64_t k0 = K * NBO;
-        int64_t rend = row_end ? row_end[K] : ncols;
-        if (rend < k0 + NBO) rend = k0 + NBO;
-        if (rend > ncols) rend = ncols;
-        for (int jsub = 0; jsub < NBO / NB; ++jsub) {
-            int64_t d = K * (NBO / NB) + jsub;
-            int64_t rows1 = rend - (d + 1) * NB;
-            if (rows1 < 0) rows1 = 0;
-            int64_t rows = rows1 + rows2;
-            int64_t blocks = rows > 0 ? (rows + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-            hipLaunchKernelGGL(k_panel, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, d, rend, r2_begin, r2_end, w, y,
-                               d_info);
-            int64_t c_hi = K * (NBO / NB) + (NBO / NB - 1);
-            if (jsub < NBO / NB - 1 && rows > 0) {
-                int64_t tiles1 = rows1 / NB, tiles2 = rows2 / NB;
-                int64_t ctiles = c_hi - d;
-                hipLaunchKernelGGL(k_upd64, dim3((unsigned)(tiles1 + tiles2), (unsigned)ctiles), dim3(256), 0, s, A, ld,
-                                   d, c_hi, tiles1, r2_begin);
-            }
+        CholStep st;
+        for (int i = 0; i < SRK_MAX_CHUNKS; ++i) st.v[i] = -1;
+        for (int i = 0; i < n; ++i) {
+            const int64_t ncols = B.it[i].ncols;
+            if (K >= ncols / NBO) continue;
+            int64_t rend = H[i].row_end ? H[i].row_end[K] : ncols;
+            if (rend < k0 + NBO) rend = k0 + NBO;
+            if (rend > ncols) rend = ncols;
+            st.v[i] = rend;
         }
-        int64_t c_first = k0 + NBO;
-        int64_t T1 = (rend - c_first) / TL;
-        if (T1 < 0) T1 = 0;
-        int64_t T = T1 + rows2 / TL;
+        for (int jsub = 0; jsub < NBO / NB; ++jsub) {
+            const int64_t d = K * (NBO / NB) + jsub;
+            int64_t blocks = 1, tiles = 0;
+            for (int i = 0; i < n; ++i) {
+                if (st.v[i] < 0) continue;
+                int64_t rows1 = st.v[i] - (d + 1) * NB;
+                if (rows1 < 0) rows1 = 0;
+                const int64_t rows2 = B.it[i].r2_end - B.it[i].r2_begin;
+                const int64_t rows = rows1 + rows2;
+                if (rows > 0) blocks = std::max(blocks, (rows + PANEL_ROWS - 1) / PANEL_ROWS);
+                tiles = std::max(tiles, rows1 / NB + rows2 / NB);
+            }
+            hipLaunchKernelGGL(k_panel, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, st, d, d_info);
+            const int64_t c_hi = K * (NBO / NB) + (NBO / NB - 1);
+            if (jsub < NBO / NB - 1 && tiles > 0)
+                hipLaunchKernelGGL(k_upd64, dim3((unsigned)tiles, (unsigned)(c_hi - d), (unsigned)n), dim3(256), 0, s, B,
+                                   st, d, c_hi);
+        }
+        const int64_t c_first = k0 + NBO;
+        int64_t T = 0;
+        for (int i = 0; i < n; ++i) {
+            if (st.v[i] < 0) continue;
+            int64_t T1 = (st.v[i] - c_first) / TL;
+            if (T1 < 0) T1 = 0;
+            T = std::max(T, T1 + (B.it[i].r2_end - B.it[i].r2_begin) / TL);
+        }
         if (ev_pairs) hipEventRecord(ev_pairs[2 * K], s);
         if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
-            int64_t T64 = 2 * T;
-            hipLaunchKernelGGL(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2)), dim3(256), 0, s, A, ld, k0, c_first,
-                               2 * T1, r2_begin);
+            const int64_t T64 = 2 * T;
+            hipLaunchKernelGGL(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
+                               c_first);
         } else if (T > 0) {
-            int64_t pairs = T * (T + 1) / 2;
-            hipLaunchKernelGGL(k_trail, dim3((unsigned)pairs), dim3(256), 0, s, A, ld, k0, c_first, T1, r2_begin);
+            hipLaunchKernelGGL(k_trail, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
+                               c_first);
         }
         if (ev_pairs) hipEventRecord(ev_pairs[2 * K + 1], s);
     }
 }
 
-// chol_bwd: x = L^-T y over the first `ncols` columns (the border part, if any, has been folded into y already)
-static void chol_bwd(hipStream_t s, int64_t ld, const double* A, int64_t ncols, const int64_t* col_begin, double* dinv,
-                     double* y, double* x)
+// chol_bwd: x = L^-T y over the first `ncols` columns of every item (the border part, if any, has been folded into y
+// already).  Launch t serves outer panel nout_i - 1 - t of item i.
+static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H)
 {
-    const int64_t nout = ncols / NBO;
-    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(ncols / NB)), dim3(64), 0, s, A, ld, dinv);
-    for (int64_t K = nout - 1; K >= 0; --K) {
-        int64_t cb = col_begin ? col_begin[K * (NBO / NB)] : 0;
-        for (int q = 1; q < NBO / NB; ++q)
-            if (col_begin) cb = cb < col_begin[K * (NBO / NB) + q] ? cb : col_begin[K * (NBO / NB) + q];
-        if (cb > K * NBO) cb = K * NBO;
-        int64_t cols = K * NBO - cb;
-        int64_t blocks = cols > 0 ? (cols + 255) / 256 : 1;
-        hipLaunchKernelGGL(k_bwd256, dim3((unsigned)blocks), dim3(256), 0, s, A, ld, K, cb, dinv, y, x);
+    int64_t nout = 0;
+    for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
+    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(nout * (NBO / NB)), 1, (unsigned)n), dim3(64), 0, s, B);
+    for (int64_t t = 0; t < nout; ++t) {
+        CholStep Kst, cbeg;
+        int64_t blocks = 1;
+        for (int i = 0; i < SRK_MAX_CHUNKS; ++i) Kst.v[i] = -1, cbeg.v[i] = 0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t K = B.it[i].ncols / NBO - 1 - t;
+            if (K < 0) continue;
+            const int64_t* col_begin = H[i].col_begin;
+            int64_t cb = col_begin ? col_begin[K * (NBO / NB)] : 0;
+            for (int q = 1; q < NBO / NB; ++q)
+                if (col_begin) cb = std::min(cb, col_begin[K * (NBO / NB) + q]);
+            if (cb > K * NBO) cb = K * NBO;
+            const int64_t cols = K * NBO - cb;
+            if (cols > 0) blocks = std::max(blocks, (cols + 255) / 256);
+            Kst.v[i] = K;
+            cbeg.v[i] = cb;
+        }
+        hipLaunchKernelGGL(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg);
     }
 }
 
@@ -645,8 +730,11 @@ static void chol_bwd(hipStream_t s, int64_t ld, const double* A, int64_t ncols, 
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
                     const int64_t* row_end, const int64_t* col_begin, double* dinv, hipEvent_t* ev_pairs)
 {
-    chol_factor(s, ld, A, ld, w, y, d_info, row_end, ld, ld, ev_pairs);
-    chol_bwd(s, ld, A, ld, col_begin, dinv, y, x);
+    CholBatch B{};
+    B.it[0] = CholItem{ A, w, y, x, dinv, ld, ld, ld, ld };
+    CholHostItem H{ row_end, col_begin };
+    chol_factor(s, B, 1, &H, d_info, ev_pairs);
+    chol_bwd(s, B, 1, &H);
     hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }
 
@@ -655,19 +743,24 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
 // of `sepw` variables (sepw >= the bandwidth, so chunks do not touch each other): every chunk
 //     [ A_c   B_c^T ]      A_c : the chunk (skyline),  B_c : its couplings to the separator above and below
 //     [ B_c    0    ]
-// is factorised INDEPENDENTLY on its own stream (the separator rows ride along as border rows of every panel and end
-// up holding Y_c = B_c L_c^-T, the border block holds -Y_c Y_c^T); the small separator system
-// C - sum_c Y_c Y_c^T is solved next, and the chunks are back-substituted concurrently again.  Exact arithmetic is
-// the same as one Cholesky of a re-ordered matrix; the dependency chain is n / P + sepw (P - 1) pivots instead of n.
+// is factorised INDEPENDENTLY, as one item of a batch (the separator rows ride along as border rows of every panel
+// and end up holding Y_c = B_c L_c^-T, the border block holds -Y_c Y_c^T); the small separator system
+// C - sum_c Y_c Y_c^T is solved next, and the chunks are back-substituted as a batch again.  Exact arithmetic is the
+// same as one Cholesky of a re-ordered matrix; the dependency chain is n / P + sepw (P - 1) pivots instead of n.
+// No atomics and a fixed summation order: results are bit-reproducible.
 
-// one workgroup per local row of the chunk matrix
+// one workgroup per local row of a chunk matrix; blockIdx.z = chunk
 __global__ __launch_bounds__(256) void k_chunk_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
-                                                      const int64_t* __restrict__ env_col, int64_t a, int64_t nc,
-                                                      int64_t sepw, int has_top, int has_bot, double* __restrict__ Ac,
-                                                      int64_t ldc, double* __restrict__ wc)
+                                                      const int64_t* __restrict__ env_col, const CholBatch B,
+                                                      const CholStep first, int64_t sepw, int P)
 {
+    const int z = blockIdx.z;
+    const int64_t ldc = B.it[z].ld, nc = B.it[z].ncols, a = first.v[z];
     const int64_t i = blockIdx.x;
-    double* dst = Ac + i * ldc;
+    if (i >= ldc) return;
+    const bool has_top = z > 0, has_bot = z < P - 1;
+    double* __restrict__ wc = B.it[z].w;
+    double* dst = B.it[z].A + i * ldc;
     if (i < nc) {
         const int64_t g = a + i;
         int64_t c0 = env_col[g / 128] - a;
@@ -709,12 +802,16 @@ __global__ __launch_bounds__(256) void k_sep_gather(const double* __restrict__ S
     if (threadIdx.x == 0) ws[i] = rhs[g];
 }
 
-// add a chunk's border block (-Y Y^T) and border rhs into the separator system (one launch per chunk, in order)
-__global__ __launch_bounds__(256) void k_sep_reduce(const double* __restrict__ Ac, int64_t ldc, const double* __restrict__ wc,
-                                                    int64_t nc, int64_t sepw, int64_t top_sep /* -1 = none */,
-                                                    int64_t bot_sep /* -1 = none */, double* __restrict__ Cs,
-                                                    int64_t lds, double* __restrict__ ws)
+// add the chunks' border blocks (-Y Y^T) and border right-hand sides into the separator system.  Chunk c touches
+// separators c-1 and c, so the chunks of one parity touch disjoint entries: two launches (even, odd), no atomics.
+__global__ __launch_bounds__(256) void k_sep_reduce(const CholBatch B, int parity, int P, int64_t sepw,
+                                                    double* __restrict__ Cs, int64_t lds, double* __restrict__ ws)
 {
+    const int c = 2 * (int)blockIdx.z + parity;
+    if (c >= P) return;
+    const int64_t top_sep = c > 0 ? c - 1 : -1, bot_sep = c < P - 1 ? c : -1;
+    const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;
+    const double* __restrict__ Ac = B.it[c].A;
     const int64_t u2 = blockIdx.x; // border row 0 .. 2 sepw - 1
     const int64_t su = u2 < sepw ? top_sep : bot_sep;
     if (su < 0) return;
@@ -726,15 +823,25 @@ __global__ __launch_bounds__(256) void k_sep_reduce(const double* __restrict__ A
         const int64_t cv = sv * sepw + (v2 < sepw ? v2 : v2 - sepw);
         Cs[ru * lds + cv] += src[v2];
     }
-    if (threadIdx.x == 0) ws[ru] += wc[nc + u2];
+    if (threadIdx.x == 0) ws[ru] += B.it[c].w[nc + u2];
 }
 
-// border part of the chunk's solution = the separator solution; then fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i]
-__global__ __launch_bounds__(256) void k_bwd_border(const double* __restrict__ Ac, int64_t ldc, int64_t nc, int64_t sepw,
-                                                    int64_t top_sep, int64_t bot_sep, const double* __restrict__ xs,
-                                                    double* __restrict__ yc)
+// separator part of the global solution
+__global__ __launch_bounds__(256) void k_sep_scatter(int64_t n, int64_t sepw, const int64_t* __restrict__ sep_start,
+                                                     const double* __restrict__ xs, double* __restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[sep_start[i / sepw] + i % sepw] = xs[i];
+}
+
+// border part of a chunk's solution = the separator solution; fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i]
+__global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs)
 {
     __shared__ double sx[1024];
+    const int c = blockIdx.z;
+    const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;
+    if ((int64_t)blockIdx.x * 256 >= nc) return;
+    const int64_t top_sep = c > 0 ? c - 1 : -1, bot_sep = c < P - 1 ? c : -1;
     for (int64_t u2 = threadIdx.x; u2 < 2 * sepw; u2 += 256) {
         const int64_t su = u2 < sepw ? top_sep : bot_sep;
         sx[u2] = su < 0 ? 0.0 : xs[su * sepw + (u2 < sepw ? u2 : u2 - sepw)];
@@ -742,61 +849,54 @@ __global__ __launch_bounds__(256) void k_bwd_border(const double* __restrict__ A
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= nc) return;
-    const double* col = Ac + nc * ldc + j;
+    const double* col = B.it[c].A + nc * ldc + j;
     double acc = 0;
 #pragma unroll 8
     for (int64_t u2 = 0; u2 < 2 * sepw; ++u2) acc += col[u2 * ldc] * sx[u2];
-    yc[j] -= acc;
+    B.it[c].y[j] -= acc;
 }
 
-__global__ void k_scatter(int64_t n, const double* __restrict__ src, double* __restrict__ dst)
+// interior part of the global solution
+__global__ __launch_bounds__(256) void k_chunk_scatter(const CholBatch B, const CholStep first, double* __restrict__ x)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < B.it[blockIdx.z].ncols) x[first.v[blockIdx.z] + j] = B.it[blockIdx.z].x[j];
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
                             double* x, const int64_t* d_env_col, int* d_info)
 {
     const int P = pl.P;
-    const int64_t sepw = pl.sepw;
-    // fork: chunk streams wait for the assembled system
-    hipEventRecord(pl.ev_fork, s);
+    const int64_t sepw = pl.sepw, lds = pl.lds;
+    CholBatch B{}, Bs{};
+    CholStep first;
+    CholHostItem H[SRK_MAX_CHUNKS], Hs{ pl.s_row_end.data(), pl.s_col_begin.data() };
+    int64_t max_ldc = 0, max_nc = 0;
+    for (int c = 0; c < SRK_MAX_CHUNKS; ++c) first.v[c] = 0;
     for (int c = 0; c < P; ++c) {
-        hipStream_t cs = pl.streams[c];
-        hipStreamWaitEvent(cs, pl.ev_fork, 0);
-        const int64_t nc = pl.n[c], ldc = pl.ldc[c];
-        hipLaunchKernelGGL(k_chunk_gather, dim3((unsigned)ldc), dim3(256), 0, cs, S, ld, rhs, d_env_col, pl.a[c], nc, sepw,
-                           c > 0, c < P - 1, pl.Ac[c], ldc, pl.wc[c]);
-        chol_factor(cs, ldc, pl.Ac[c], nc, pl.wc[c], pl.yc[c], d_info, pl.row_end[c].data(), nc, ldc, nullptr);
-        hipEventRecord(pl.ev_join[c], cs);
+        B.it[c] = CholItem{ pl.Ac[c], pl.wc[c], pl.yc[c], pl.xc[c], pl.dinvc[c], pl.ldc[c], pl.n[c], pl.n[c], pl.ldc[c] };
+        H[c] = CholHostItem{ pl.row_end[c].data(), pl.col_begin[c].data() };
+        first.v[c] = pl.a[c];
+        max_ldc = std::max(max_ldc, pl.ldc[c]);
+        max_nc = std::max(max_nc, pl.n[c]);
     }
-    // separator system on the main stream (its gather overlaps the chunk factorisations)
-    const int64_t lds = pl.lds;
+    Bs.it[0] = CholItem{ pl.Cs, pl.ws, pl.ys, pl.xs, pl.dinvs, lds, lds, lds, lds };
+    const unsigned cblocks = (unsigned)((max_nc + 255) / 256);
+
+    hipLaunchKernelGGL(k_chunk_gather, dim3((unsigned)max_ldc, 1, (unsigned)P), dim3(256), 0, s, S, ld, rhs, d_env_col, B,
+                       first, sepw, P);
     hipLaunchKernelGGL(k_sep_gather, dim3((unsigned)lds), dim3(256), 0, s, S, ld, rhs, pl.d_sep_start, sepw, pl.Cs, lds,
                        pl.ws);
-    for (int c = 0; c < P; ++c) {
-        hipStreamWaitEvent(s, pl.ev_join[c], 0);
-        hipLaunchKernelGGL(k_sep_reduce, dim3((unsigned)(2 * sepw)), dim3(256), 0, s, pl.Ac[c], pl.ldc[c], pl.wc[c],
-                           pl.n[c], sepw, (int64_t)(c > 0 ? c - 1 : -1), (int64_t)(c < P - 1 ? c : -1), pl.Cs, lds, pl.ws);
-    }
-    chol_factor(s, lds, pl.Cs, lds, pl.ws, pl.ys, d_info, pl.s_row_end.data(), lds, lds, nullptr);
-    chol_bwd(s, lds, pl.Cs, lds, pl.s_col_begin.data(), pl.dinvs, pl.ys, pl.xs);
-    for (int c = 0; c + 1 < P; ++c) // separator variables of the global solution
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((sepw + 255) / 256)), dim3(256), 0, s, sepw, pl.xs + c * sepw,
-                           x + pl.a[c] + pl.n[c]);
-    hipEventRecord(pl.ev_fork2, s);
-    // back-substitution of the chunks, concurrently again
-    for (int c = 0; c < P; ++c) {
-        hipStream_t cs = pl.streams[c];
-        hipStreamWaitEvent(cs, pl.ev_fork2, 0);
-        const int64_t nc = pl.n[c], ldc = pl.ldc[c];
-        hipLaunchKernelGGL(k_bwd_border, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, cs, pl.Ac[c], ldc, nc, sepw,
-                           (int64_t)(c > 0 ? c - 1 : -1), (int64_t)(c < P - 1 ? c : -1), pl.xs, pl.yc[c]);
-        chol_bwd(cs, ldc, pl.Ac[c], nc, pl.col_begin[c].data(), pl.dinvc[c], pl.yc[c], pl.xc[c]);
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, cs, nc, pl.xc[c], x + pl.a[c]);
-        hipEventRecord(pl.ev_join[c], cs);
-    }
-    for (int c = 0; c < P; ++c) hipStreamWaitEvent(s, pl.ev_join[c], 0);
+    chol_factor(s, B, P, H, d_info, nullptr);
+    for (int parity = 0; parity < 2; ++parity)
+        hipLaunchKernelGGL(k_sep_reduce, dim3((unsigned)(2 * sepw), 1, (unsigned)((P + 1) / 2)), dim3(256), 0, s, B, parity,
+                           P, sepw, pl.Cs, lds, pl.ws);
+    chol_factor(s, Bs, 1, &Hs, d_info, nullptr);
+    chol_bwd(s, Bs, 1, &Hs);
+    hipLaunchKernelGGL(k_sep_scatter, dim3((unsigned)((lds + 255) / 256)), dim3(256), 0, s, lds, sepw, pl.d_sep_start,
+                       pl.xs, x);
+    hipLaunchKernelGGL(k_bwd_border, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
+    chol_bwd(s, B, P, H);
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, first, x);
     hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }

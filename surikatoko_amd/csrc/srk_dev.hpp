@@ -83,7 +83,7 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
 
 // ---- chunked (bordered block-diagonal) solve of a banded reduced camera system (srk_chol.hip) ----
 #include <vector>
-#define SRK_MAX_CHUNKS 8
+#define SRK_MAX_CHUNKS 16
 struct SrkChunkPlan {
     int P = 0;                       // number of chunks; < 2 = not used
     int64_t sepw = 256;              // separator width (variables), >= bandwidth
@@ -100,8 +100,6 @@ struct SrkChunkPlan {
     double *Cs = nullptr, *ws = nullptr, *ys = nullptr, *xs = nullptr, *dinvs = nullptr;
     std::vector<int64_t> s_row_end, s_col_begin;
     int64_t* d_sep_start = nullptr;  // device: first global variable of separator c
-    hipStream_t streams[SRK_MAX_CHUNKS]{};
-    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[SRK_MAX_CHUNKS]{};
 };
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
                             double* x, const int64_t* d_env_col, int* d_info);
