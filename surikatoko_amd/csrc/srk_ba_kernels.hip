@@ -669,6 +669,9 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         for (int pl = 0; pl < nb; ++pl) {
             const double* w = sW[pl];
             const double* yv = sY[pl];
+#ifdef SRK_SCH_NOACC
+            if (d.N >= 0) continue;
+#endif
 #pragma unroll
             for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
                 if (!act[s]) continue;
@@ -724,6 +727,9 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
             int b = cw / 10, cc = cw - b * 10;
             int64_t row = 10 * (int64_t)sF[a] + r, col = 10 * (int64_t)sF[b] + cc;
             if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
+#ifdef SRK_SCH_NOFLUSH
+            if (d.N >= 0) continue;
+#endif
             atomicAdd(&S[row * d.ld + col], -sBuf[e]);
         }
         a0 = a1;

@@ -545,32 +545,92 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
 
 // ---------------------------------------------------------------- backward substitution L^T x = y
 // k_dinv: Dinv[d] = L_dd^-1 (lower triangular, 64x64) for every diagonal tile at once -- it turns the 64 dependent
-// steps of each triangular solve into one small matrix-vector product.
-__global__ __launch_bounds__(64) void k_dinv(const CholBatch B)
+// steps of each triangular solve into one small matrix-vector product.  Blocked inversion: the four 16x16 diagonal
+// blocks by register-resident forward substitution (16 dependent steps), then two levels of
+//     [ L11  0  ]^-1   [ Z11            0  ]
+//     [ L21 L22 ]    = [ -Z22 L21 Z11  Z22 ]
+// as small LDS matrix products over all 256 threads (a 64-step substitution per column took ~100 us per launch).
+__global__ __launch_bounds__(256) void k_dinv(const CholBatch B)
 {
     __shared__ double sL[NB][NB + 1];
     __shared__ double sZ[NB][NB + 1];
+    __shared__ double sT[32][33];
     const int64_t k0 = (int64_t)blockIdx.x * NB;
     if (k0 >= B.it[blockIdx.z].ncols) return;
     const double* __restrict__ A = B.it[blockIdx.z].A;
     double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
     const int64_t ld = B.it[blockIdx.z].ld;
     const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += 64) {
+    for (int e = t; e < NB * NB; e += 256) {
         int i = e >> 6, c = e & 63;
         sL[i][c] = (c <= i) ? A[(k0 + i) * ld + k0 + c] : 0.0;
+        sZ[i][c] = 0.0;
     }
     __syncthreads();
-    // thread t: column t of L^-1 by forward substitution (z_i = (e_t[i] - sum_{m<i} L_im z_m) / L_ii); the sums run
-    // in lock step over (i, m), so L_im is an LDS broadcast and z_m[t] is bank-conflict free
-    for (int i = 0; i < NB; ++i) {
-        double sum = (i == t) ? 1.0 : 0.0;
-        for (int m = 0; m < i; ++m) sum -= sL[i][m] * ((m >= t) ? sZ[m][t] : 0.0);
-        sZ[i][t] = (i >= t) ? sum / sL[i][i] : 0.0;
+    if (t < 64) { // thread (b, c): column c of the inverse of diagonal block b, right-looking in registers
+        const int o = 16 * (t >> 4), c = t & 15;
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double z = (i >= c) ? acc[i] / sL[o + i][o + i] : 0.0;
+            sZ[o + i][o + c] = z;
+#pragma unroll
+            for (int k = i + 1; k < 16; ++k) acc[k] = fma(-sL[o + k][o + i], z, acc[k]);
+        }
+    }
+    __syncthreads();
+    // level 32: pairs (block 1 | block 0) and (block 3 | block 2); thread -> outputs idx = t, t + 256
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int idx = t + 256 * h, pr = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        const int o1 = 32 * pr, o2 = o1 + 16;
+        double sum = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sum = fma(sL[o2 + i][o1 + m], sZ[o1 + m][o1 + j], sum);
+        sT[16 * pr + i][j] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int idx = t + 256 * h, pr = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        const int o1 = 32 * pr, o2 = o1 + 16;
+        double sum = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sum = fma(sZ[o2 + i][o2 + m], sT[16 * pr + m][j], sum);
+        sZ[o2 + i][o1 + j] = -sum;
+    }
+    __syncthreads();
+    // level 64: T = L21 Z11 (32x32), X = -Z22 T; thread -> outputs (i, j), (i + 8, j), (i + 16, j), (i + 24, j)
+    {
+        const int i0 = t >> 5, j = t & 31;
+        double sum[4] = { 0, 0, 0, 0 };
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            const double zv = sZ[m][j];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sum[h] = fma(sL[32 + i0 + 8 * h][m], zv, sum[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sT[i0 + 8 * h][j] = sum[h];
+    }
+    __syncthreads();
+    {
+        const int i0 = t >> 5, j = t & 31;
+        double sum[4] = { 0, 0, 0, 0 };
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            const double tv = sT[m][j];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sum[h] = fma(sZ[32 + i0 + 8 * h][32 + m], tv, sum[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sZ[32 + i0 + 8 * h][j] = -sum[h];
     }
     __syncthreads();
     double* out = Dinv + (int64_t)blockIdx.x * NB * NB;
-    for (int e = t; e < NB * NB; e += 64) out[e] = sZ[e >> 6][e & 63];
+    for (int e = t; e < NB * NB; e += 256) out[e] = sZ[e >> 6][e & 63];
 }
 
 // step K (descending, 256 rows): x_K = L_KK^-T y_K by four tile back-substitutions with the explicit tile inverses
@@ -700,7 +760,7 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
-    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(nout * (NBO / NB)), 1, (unsigned)n), dim3(64), 0, s, B);
+    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(nout * (NBO / NB)), 1, (unsigned)n), dim3(256), 0, s, B);
     for (int64_t t = 0; t < nout; ++t) {
         CholStep Kst, cbeg;
         int64_t blocks = 1;
