@@ -49,7 +49,7 @@ struct srk_ba {
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
     DevBuf grp_first, grp_count, gen_list, wg_jmin;
-    int64_t n_groups = 0, n_generic = 0;
+    int64_t n_groups = 0, n_groups_wide = 0, n_generic = 0;
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
@@ -501,6 +501,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     obs_uv = ouv.data();
     // runs of identical frame lists -> grouped kernel (<= SRK_GRP_MAXNF_HOST frames); the rest -> generic kernel
     std::vector<int32_t> grp_first, grp_count, gen_list;
+    int64_t n_wide = 0;
     for (int64_t i = 0; i < N;) {
         int64_t j = i + 1;
         while (j < N && same_list(i, j)) ++j; // internal indices: row_ptr / obs_frame now are the permuted arrays
@@ -509,6 +510,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             for (int64_t k = i; k < j; k += SRK_GRP_MAXPTS_HOST) {
                 grp_first.push_back((int32_t)k);
                 grp_count.push_back((int32_t)std::min<int64_t>(SRK_GRP_MAXPTS_HOST, j - k));
+                if (nf > SRK_GRP_NF1_HOST) ++n_wide;
             }
         } else {
             for (int64_t k = i; k < j; ++k)
@@ -517,6 +519,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         i = j;
     }
     h->n_groups = (int64_t)grp_first.size();
+    h->n_groups_wide = n_wide;
     h->n_generic = (int64_t)gen_list.size();
     SrkDims d{};
     d.N = N;
@@ -753,7 +756,7 @@ static int phase_schur(srk_ba* h, double c)
     HIPCHK(h, hipMemsetAsync(h->rhs.p, 0, 8 * d.ld, s));
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W),
                              P<double>(h->Vg), P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->grp_first),
-                             P<int32_t>(h->grp_count), h->n_groups);
+                             P<int32_t>(h->grp_count), h->n_groups, h->n_groups_wide);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());

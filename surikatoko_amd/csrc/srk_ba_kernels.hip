@@ -584,136 +584,179 @@ void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* 
 // ------------------------------------------------------------------ K3g: Schur accumulation, grouped landmarks
 // Landmarks are stored sorted by their frame list, so landmarks that see exactly the same frames are contiguous.
 // One workgroup takes a run of such landmarks (<= SRK_GRP_MAXPTS) and keeps the whole lower block triangle of their
-// common nf x nf frame-pair blocks in REGISTERS (2x10 strips, <= SRK_GRP_SLOTS per thread); every landmark's 3x3
-// elimination block is inverted once, W_i and Y_i = E_i^-1 W_i are staged in LDS, and the sums leave the chip once
-// per run as fp64 atomics -- ~100x fewer atomic bytes than one flush per landmark.
+// common nf x nf frame-pair blocks in REGISTERS (5x10 half blocks, SLOTS per thread); every landmark's 3x3
+// elimination block is inverted once up front, W_i and Y_i = E_i^-1 W_i are staged in LDS four landmarks at a time
+// (the next four are already in flight in registers while these are multiplied), and the sums leave the chip once per
+// run as fp64 atomics -- ~100x fewer atomic bytes than one flush per landmark.
+// The accumulation is LDS-bandwidth bound (every operand of the rank-3 updates is an LDS read): a 5x10 register tile
+// needs 15 operands per 50 FMAs, against 12 per 20 for the 2x10 strips this kernel started with.
 #define SRK_GRP_THREADS 512
-#define SRK_GRP_SLOTS 3
-#define SRK_GRP_MAXNF 24   // nf (nf + 1) / 2 * 5 strips <= SRK_GRP_THREADS * SRK_GRP_SLOTS
-#define SRK_GRP_PB 4       // landmarks staged per barrier pair
+#define SRK_GRP_MAXNF 24     // nf (nf + 1) half blocks <= SRK_GRP_THREADS * 2
+#define SRK_GRP_NF1 21       // nf (nf + 1) <= SRK_GRP_THREADS: one half block per thread
+#define SRK_GRP_MAXPTS 128
+#define SRK_GRP_PB 4         // landmarks staged per barrier round
+#define SRK_GRP_WS 36        // LDS doubles per (landmark, frame) of W: 3 x (5 | pad | 5 | pad), halves 16-byte aligned
+#define SRK_GRP_PRE 6        // prefetch registers: PB * MAXNF * 30 / THREADS, rounded up
+static_assert(SRK_GRP_MAXNF == SRK_GRP_MAXNF_HOST && SRK_GRP_NF1 == SRK_GRP_NF1_HOST && SRK_GRP_MAXPTS == SRK_GRP_MAXPTS_HOST,
+              "host / kernel grouping constants differ");
+static_assert(SRK_GRP_PRE * SRK_GRP_THREADS >= 30 * SRK_GRP_PB * SRK_GRP_MAXNF, "staging map too small");
+static_assert(SRK_GRP_NF1 * (SRK_GRP_NF1 + 1) <= SRK_GRP_THREADS && SRK_GRP_MAXNF * (SRK_GRP_MAXNF + 1) <= 2 * SRK_GRP_THREADS,
+              "half blocks do not fit the thread slots");
 
+template <int SLOTS>
 __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_frame,
     const double* __restrict__ W, const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count)
 {
     // one LDS arena: W | Y staging during the accumulation, then the staging buffer of the coalesced flush
-    __shared__ __attribute__((aligned(16))) double sBuf[2 * SRK_GRP_PB * SRK_GRP_MAXNF * 30];
-    double (*sW)[SRK_GRP_MAXNF * 30] = reinterpret_cast<double (*)[SRK_GRP_MAXNF * 30]>(sBuf);
-    double (*sY)[SRK_GRP_MAXNF * 30] =
-        reinterpret_cast<double (*)[SRK_GRP_MAXNF * 30]>(sBuf + SRK_GRP_PB * SRK_GRP_MAXNF * 30);
-    __shared__ double sE[SRK_GRP_PB][12];
+    constexpr int W_LM = SRK_GRP_MAXNF * SRK_GRP_WS, Y_LM = SRK_GRP_MAXNF * 30; // doubles per staged landmark
+    constexpr int CAP = SRK_GRP_PB * (W_LM + Y_LM);
+    __shared__ __attribute__((aligned(16))) double sBuf[CAP];
+    __shared__ double sE[SRK_GRP_MAXPTS][12];
     __shared__ int32_t sF[SRK_GRP_MAXNF];
+    double* const sW = sBuf;
+    double* const sY = sBuf + SRK_GRP_PB * W_LM;
     const int tid = threadIdx.x;
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
     const int64_t o0 = row_ptr[p0];
     const int nf = (int)(row_ptr[p0 + 1] - o0);
+    if ((SLOTS == 1) != (nf <= SRK_GRP_NF1)) return; // the other instantiation takes this run
     if (tid < nf) sF[tid] = obs_frame[o0 + tid];
-    // strip u -> (block pair (a, b), b <= a ; rows r0, r0 + 1)
-    const int n_strips = nf * (nf + 1) / 2 * 5;
-    int offW[SRK_GRP_SLOTS], offY[SRK_GRP_SLOTS], sa[SRK_GRP_SLOTS], sb[SRK_GRP_SLOTS], sr[SRK_GRP_SLOTS];
-    bool act[SRK_GRP_SLOTS];
+    if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
+        double Einv[9], g[3];
+        bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
 #pragma unroll
-    for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+        for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
+    }
+    // half block u -> (block pair (a, b), b <= a ; rows 5 hf .. 5 hf + 4)
+    const int n_half = nf * (nf + 1);
+    int offW[SLOTS], offY[SLOTS], sa[SLOTS], sb[SLOTS], sh[SLOTS];
+    bool act[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
         int u = tid + s * SRK_GRP_THREADS;
-        act[s] = u < n_strips;
-        int pi = act[s] ? u / 5 : 0;
-        int ru = act[s] ? u - pi * 5 : 0;
+        act[s] = u < n_half;
+        int pi = act[s] ? u >> 1 : 0;
+        int hf = act[s] ? u & 1 : 0;
         int a = (int)((sqrtf(8.0f * (float)pi + 1.0f) - 1.0f) * 0.5f);
         while ((a + 1) * (a + 2) / 2 <= pi) ++a;
         while (a * (a + 1) / 2 > pi) --a;
         int b = pi - a * (a + 1) / 2;
-        sa[s] = a; sb[s] = b; sr[s] = 2 * ru;
-        offW[s] = a * 30 + 2 * ru;
+        sa[s] = a; sb[s] = b; sh[s] = hf;
+        offW[s] = a * SRK_GRP_WS + 6 * hf;
         offY[s] = b * 30;
     }
-    double acc[SRK_GRP_SLOTS][2][10];
+    double acc[SLOTS][5][10];
 #pragma unroll
-    for (int s = 0; s < SRK_GRP_SLOTS; ++s)
+    for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int cc = 0; cc < 10; ++cc) acc[s][i][cc] = 0;
     double racc = 0; // rhs accumulator: thread t < 10 nf owns entry (a = t / 10, r = t % 10)
-    const int n30 = nf * 30;
+    // staging map (the same for every round): element idx = tid + j THREADS -> W row k = idx / (PB nf), position q in
+    // the round's PB nf consecutive observations (coalesced over q); LDS slot of (landmark q / nf, frame q % nf, k)
+    const int qn = SRK_GRP_PB * nf;
+    int goff[SRK_GRP_PRE], loff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
+#pragma unroll
+    for (int j = 0; j < SRK_GRP_PRE; ++j) {
+        int idx = tid + j * SRK_GRP_THREADS;
+        int k = idx / qn, q = idx - k * qn;
+        bool in = k < 30;
+        int pl = q / nf, a = q - pl * nf;
+        int m = k / 10, r = k - 10 * m;
+        qpos[j] = in ? q : (1 << 30);
+        goff[j] = in ? q : 0;
+        loff[j] = in ? pl * W_LM + a * SRK_GRP_WS + 12 * m + r + (r >= 5) : 0;
+        // W row k, folded into the 64-bit base below to keep the per-round address a single add
+        goff[j] |= (in ? k : 0) << 16; // q < PB * MAXNF = 96 < 65536
+    }
+    double pre[SRK_GRP_PRE];
+    auto prefetch = [&](int pb) {
+        const int nq = (np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB) * nf;
+        const double* base = W + o0 + (int64_t)pb * nf;
+#pragma unroll
+        for (int j = 0; j < SRK_GRP_PRE; ++j)
+            pre[j] = qpos[j] < nq ? base[(int64_t)(goff[j] >> 16) * d.Os + (goff[j] & 0xffff)] : 0.0;
+    };
+    prefetch(0);
     for (int pb = 0; pb < np; pb += SRK_GRP_PB) {
-        int nb = np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB;
-        __syncthreads();
-        if (tid < nb) { // 3x3 damped block inverse; a singular block contributes nothing (:1877-1881)
-            double Einv[9], g[3];
-            bool ok = point_block_inverse(Vg, d.Ns, p0 + pb + tid, c, Einv, g);
+        const int nb = np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB;
+        __syncthreads(); // the previous round's W / Y are consumed (first round: sE, sF are visible)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-                sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
-        }
-        // W of the staged landmarks: the run is contiguous in the observation arrays
-        for (int t = tid; t < nb * n30; t += SRK_GRP_THREADS) {
-            int pl = t / n30, e = t - pl * n30;
-            int k = e / nf, a = e - k * nf; // lanes walk `a` (contiguous in memory) first
-            sW[pl][a * 30 + k] = W[(int64_t)k * d.Os + o0 + (int64_t)(pb + pl) * nf + a];
-        }
+        for (int j = 0; j < SRK_GRP_PRE; ++j)
+            if (qpos[j] < nb * nf) sW[loff[j]] = pre[j];
         __syncthreads();
         for (int t = tid; t < nb * nf * 10; t += SRK_GRP_THREADS) {
             int pl = t / (nf * 10), e = t - pl * nf * 10;
             int a = e / 10, fv = e - a * 10;
-            const double* Ei = sE[pl];
-            double w0 = sW[pl][a * 30 + fv], w1 = sW[pl][a * 30 + 10 + fv], w2 = sW[pl][a * 30 + 20 + fv];
-            sY[pl][a * 30 + fv] = Ei[0] * w0 + Ei[1] * w1 + Ei[2] * w2;
-            sY[pl][a * 30 + 10 + fv] = Ei[3] * w0 + Ei[4] * w1 + Ei[5] * w2;
-            sY[pl][a * 30 + 20 + fv] = Ei[6] * w0 + Ei[7] * w1 + Ei[8] * w2;
+            const double* Ei = sE[pb + pl];
+            const double* wp = sW + pl * W_LM + a * SRK_GRP_WS + fv + (fv >= 5);
+            double w0 = wp[0], w1 = wp[12], w2 = wp[24];
+            double* yp = sY + pl * Y_LM + a * 30 + fv;
+            yp[0] = Ei[0] * w0 + Ei[1] * w1 + Ei[2] * w2;
+            yp[10] = Ei[3] * w0 + Ei[4] * w1 + Ei[5] * w2;
+            yp[20] = Ei[6] * w0 + Ei[7] * w1 + Ei[8] * w2;
         }
+        if (pb + SRK_GRP_PB < np) prefetch(pb + SRK_GRP_PB); // in flight while this round is multiplied
         __syncthreads();
         for (int pl = 0; pl < nb; ++pl) {
-            const double* w = sW[pl];
-            const double* yv = sY[pl];
+            const double* w = sW + pl * W_LM;
+            const double* yv = sY + pl * Y_LM;
 #ifdef SRK_SCH_NOACC
             if (d.N >= 0) continue;
 #endif
 #pragma unroll
-            for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+            for (int s = 0; s < SLOTS; ++s) {
                 if (!act[s]) continue;
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    double2 wv = *reinterpret_cast<const double2*>(w + offW[s] + 10 * m);
+                    const double* wp = w + offW[s] + 12 * m;
+                    const double2 w01 = *reinterpret_cast<const double2*>(wp);
+                    const double2 w23 = *reinterpret_cast<const double2*>(wp + 2);
+                    const double wr[5] = { w01.x, w01.y, w23.x, w23.y, wp[4] };
                     const double2* yp = reinterpret_cast<const double2*>(yv + offY[s] + 10 * m);
 #pragma unroll
                     for (int h = 0; h < 5; ++h) {
-                        double2 y2 = yp[h];
-                        acc[s][0][2 * h] = fma(wv.x, y2.x, acc[s][0][2 * h]);
-                        acc[s][0][2 * h + 1] = fma(wv.x, y2.y, acc[s][0][2 * h + 1]);
-                        acc[s][1][2 * h] = fma(wv.y, y2.x, acc[s][1][2 * h]);
-                        acc[s][1][2 * h + 1] = fma(wv.y, y2.y, acc[s][1][2 * h + 1]);
+                        const double2 y2 = yp[h];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            acc[s][i][2 * h] = fma(wr[i], y2.x, acc[s][i][2 * h]);
+                            acc[s][i][2 * h + 1] = fma(wr[i], y2.y, acc[s][i][2 * h + 1]);
+                        }
                     }
                 }
             }
             if (tid < nf * 10) {
                 int a = tid / 10, r = tid - a * 10;
-                const double* Eg = sE[pl] + 9;
-                racc += w[a * 30 + r] * Eg[0] + w[a * 30 + 10 + r] * Eg[1] + w[a * 30 + 20 + r] * Eg[2];
+                const double* Eg = sE[pb + pl] + 9;
+                const double* wp = w + a * SRK_GRP_WS + r + (r >= 5);
+                racc += wp[0] * Eg[0] + wp[12] * Eg[1] + wp[24] * Eg[2];
             }
         }
     }
     // flush: S -= sum F^T E^-1 F (lower block triangle), rhs += sum F^T E^-1 g, gauge rows/columns dropped.
-    // The register strips are transposed through LDS a few block rows at a time so that consecutive lanes add to
+    // The register tiles are transposed through LDS a few block rows at a time so that consecutive lanes add to
     // consecutive columns of one row of S (block row a = 10 rows of 10 (a + 1) doubles, contiguous when the frames
     // are) -- a wave-wide atomic then covers whole cache lines instead of 64 different rows.
-    constexpr int CAP = 2 * SRK_GRP_PB * SRK_GRP_MAXNF * 30;
     for (int a0 = 0; a0 < nf;) {
         int a1 = a0, used = 0;
         while (a1 < nf && used + 100 * (a1 + 1) <= CAP) { used += 100 * (a1 + 1); ++a1; }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < SRK_GRP_SLOTS; ++s) {
+        for (int s = 0; s < SLOTS; ++s) {
             if (!act[s] || sa[s] < a0 || sa[s] >= a1) continue;
             int off = 50 * (sa[s] * (sa[s] + 1) - a0 * (a0 + 1)); // sum_{a'=a0}^{a-1} 100 (a' + 1)
             int w = 10 * (sa[s] + 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int cc = 0; cc < 10; ++cc) sBuf[off + (sr[s] + i) * w + 10 * sb[s] + cc] = acc[s][i][cc];
+                for (int cc = 0; cc < 10; ++cc) sBuf[off + (5 * sh[s] + i) * w + 10 * sb[s] + cc] = acc[s][i][cc];
         }
         __syncthreads();
         for (int e = tid; e < used; e += SRK_GRP_THREADS) {
@@ -743,11 +786,15 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
 
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr,
                               const int32_t* obs_frame, const double* W, const double* Vg, double* S, double* rhs,
-                              const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups)
+                              const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups, int64_t n_wide)
 {
     if (n_groups <= 0) return;
-    hipLaunchKernelGGL(k_schur_grouped, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr,
-                       obs_frame, W, Vg, S, rhs, grp_first, grp_count);
+    if (n_wide < n_groups)
+        hipLaunchKernelGGL(k_schur_grouped<1>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr,
+                           obs_frame, W, Vg, S, rhs, grp_first, grp_count);
+    if (n_wide > 0) // runs with more than SRK_GRP_NF1 frames: two half blocks per thread
+        hipLaunchKernelGGL(k_schur_grouped<2>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr,
+                           obs_frame, W, Vg, S, rhs, grp_first, grp_count);
 }
 
 // G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark
