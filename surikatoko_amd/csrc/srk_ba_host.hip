@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -61,6 +62,7 @@ struct srk_ba {
     bool use_chunks = true;
     SrkChunkPlan plan;
     std::vector<DevBuf> plan_bufs;
+    std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
     int cur = 0; // index of the current scene buffers; 1-cur = trial
 
     // multi-GPU exchange
@@ -309,31 +311,42 @@ static int compute_cam_packs(srk_ba* h, int which)
 }
 
 // Chunked solve plan: P chunks of the variable range separated by P-1 separators at least as wide as the
-// bandwidth (so chunks are decoupled).  Used when the skyline is narrow and the system is large enough.
-static int build_chunk_plan(srk_ba* h)
+// bandwidth (so chunks are decoupled).  The separator system is block tridiagonal in units of sepw, so it is chunked
+// again (cuts aligned to those blocks) by a child plan: nested dissection of a banded system, every level one batch.
+//
+// Cost model, in units of one 256-column outer step of the blocked Cholesky (~0.17 ms on MI355X): a chunked level
+// pays its longest chunk (border rows make a step ~10% dearer), a fixed overhead for gather / reduce / scatter,
+// and the cost of its separator system.
+static double plan_cost(int64_t ld, int64_t sepw, int64_t unit, int* best_P)
 {
-    const SrkDims& d = h->d;
-    SrkChunkPlan& pl = h->plan;
-    pl.P = 0;
-    for (DevBuf& b : h->plan_bufs) dev_free(b);
-    h->plan_bufs.clear();
-    if (!h->use_envelope || !h->use_chunks) return SRK_OK;
-    int64_t maxdist = 0;
-    for (int32_t j = 0; j < d.M; ++j) maxdist = std::max<int64_t>(maxdist, 10 * (int64_t)(j - h->min_cv[(size_t)j]) + 9);
-    int64_t sepw = maxdist <= 256 ? 256 : (maxdist <= 512 ? 512 : 0);
-    if (sepw == 0) return SRK_OK;
-    // dependency chain of the chunked solve: interior / P pivots per chunk, then sepw (P - 1) for the separator system
-    int P = 0;
-    int64_t best = d.ld;
+    const double n256 = (double)(ld / SRK_CHOL_NB);
+    double best = n256;
+    int bp = 0;
     for (int p = 2; p <= SRK_MAX_CHUNKS; ++p) {
-        const int64_t inner = (d.ld - sepw * (p - 1)) / p;
-        if (inner < 2 * sepw) break; // chunks at least two separators wide
-        const int64_t chain = (inner + SRK_CHOL_NB - 1) / SRK_CHOL_NB * SRK_CHOL_NB + sepw * (p - 1);
-        if (chain < best) best = chain, P = p;
+        const int64_t interior = ld - sepw * (p - 1);
+        if (interior < (int64_t)p * sepw) break; // every chunk at least one separator wide
+        const int64_t units = interior / unit;
+        const int64_t longest = ((units + p - 1) / p) * unit;
+        const double cst = 1.1 * (double)((longest + SRK_CHOL_NB - 1) / SRK_CHOL_NB) + 0.6 + plan_cost(sepw * (p - 1), sepw, sepw, nullptr);
+        if (cst < best - 1e-9) best = cst, bp = p;
     }
+    if (best_P) *best_P = bp;
+    return best;
+}
+
+// row_end (per 256 block, multiple of 128) / col_begin (per 64 tile): the skyline of the system to be chunked
+static int make_plan(srk_ba* h, SrkChunkPlan& pl, int64_t ld, int64_t sepw, int64_t unit,
+                     const std::vector<int64_t>& row_end, const std::vector<int64_t>& col_begin)
+{
+    pl.P = 0;
+    int P = 0;
+    plan_cost(ld, sepw, unit, &P);
     if (P < 2) return SRK_OK;
-    const int64_t interior = d.ld - sepw * (P - 1);
-    const int64_t blocks = interior / SRK_CHOL_NB; // interior is a multiple of 256 (ld and sepw are)
+    const int64_t interior = ld - sepw * (P - 1);
+    const int64_t blocks = interior / unit; // ld, sepw are multiples of unit
+    if (getenv("SRK_DEBUG"))
+        fprintf(stderr, "srk_ba chunk plan: system %lld -> %d chunks of <= %lld + %d separators of %lld\n", (long long)ld, P,
+                (long long)(((blocks + P - 1) / P) * unit), P - 1, (long long)sepw);
     pl.sepw = sepw;
     pl.lds = sepw * (P - 1);
     std::vector<int64_t> sep_start((size_t)(P - 1));
@@ -347,7 +360,7 @@ static int build_chunk_plan(srk_ba* h)
     for (int c = 0; c < P; ++c) {
         int64_t nb = blocks / P + (c < blocks % P ? 1 : 0);
         pl.a[c] = pos;
-        pl.n[c] = nb * SRK_CHOL_NB;
+        pl.n[c] = nb * unit;
         pl.ldc[c] = pl.n[c] + 2 * sepw;
         pos += pl.n[c];
         if (c < P - 1) {
@@ -363,12 +376,12 @@ static int build_chunk_plan(srk_ba* h)
         if (!pl.Ac[c] || !pl.wc[c] || !pl.yc[c] || !pl.xc[c] || !pl.dinvc[c]) return SRK_E_NOMEM;
         pl.row_end[c].assign((size_t)(nc / SRK_CHOL_NB), 0);
         for (int64_t K = 0; K < nc / SRK_CHOL_NB; ++K) {
-            int64_t rg = h->row_end_h[(size_t)(pl.a[c] / SRK_CHOL_NB + K)] - pl.a[c];
+            int64_t rg = row_end[(size_t)(pl.a[c] / SRK_CHOL_NB + K)] - pl.a[c];
             pl.row_end[c][(size_t)K] = std::min<int64_t>(std::max<int64_t>(rg, SRK_CHOL_NB * (K + 1)), nc);
         }
         pl.col_begin[c].assign((size_t)(nc / 64), 0);
         for (int64_t q = 0; q < nc / 64; ++q)
-            pl.col_begin[c][(size_t)q] = std::max<int64_t>(h->col_begin_h[(size_t)(pl.a[c] / 64 + q)] - pl.a[c], 0);
+            pl.col_begin[c][(size_t)q] = std::max<int64_t>(col_begin[(size_t)(pl.a[c] / 64 + q)] - pl.a[c], 0);
     }
     const int64_t lds = pl.lds;
     pl.Cs = (double*)alloc((size_t)(8 * lds * lds), true);
@@ -377,7 +390,8 @@ static int build_chunk_plan(srk_ba* h)
     pl.xs = (double*)alloc((size_t)(8 * lds), true);
     pl.dinvs = (double*)alloc((size_t)(8 * 64 * lds), false);
     pl.d_sep_start = (int64_t*)alloc((size_t)(8 * (P - 1)), false);
-    if (!pl.Cs || !pl.ws || !pl.ys || !pl.xs || !pl.dinvs || !pl.d_sep_start) return SRK_E_NOMEM;
+    pl.d_sep_env = (int64_t*)alloc((size_t)(8 * (lds / 128)), false);
+    if (!pl.Cs || !pl.ws || !pl.ys || !pl.xs || !pl.dinvs || !pl.d_sep_start || !pl.d_sep_env) return SRK_E_NOMEM;
     HIPCHK(h, hipMemcpyAsync(pl.d_sep_start, sep_start.data(), (size_t)(8 * (P - 1)), hipMemcpyHostToDevice, h->stream));
     // separators only couple with their neighbours (through the chunk between them): block tridiagonal skyline
     pl.s_row_end.assign((size_t)(lds / SRK_CHOL_NB), 0);
@@ -390,9 +404,35 @@ static int build_chunk_plan(srk_ba* h)
         int64_t c = (64 * q) / sepw;
         pl.s_col_begin[(size_t)q] = std::max<int64_t>(c - 1, 0) * sepw;
     }
+    std::vector<int64_t> sep_env((size_t)(lds / 128));
+    for (int64_t t = 0; t < lds / 128; ++t) sep_env[(size_t)t] = pl.s_col_begin[(size_t)(2 * t)];
+    HIPCHK(h, hipMemcpyAsync(pl.d_sep_env, sep_env.data(), (size_t)(8 * (lds / 128)), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the separator system, chunked again when that shortens its chain
+    h->plan_children.emplace_back(new SrkChunkPlan());
+    SrkChunkPlan* child = h->plan_children.back().get();
+    int rc = make_plan(h, *child, lds, sepw, sepw, pl.s_row_end, pl.s_col_begin);
+    if (rc != SRK_OK) return rc;
+    pl.child = child->P >= 2 ? child : nullptr;
     pl.P = P;
     return SRK_OK;
+}
+
+static int build_chunk_plan(srk_ba* h)
+{
+    const SrkDims& d = h->d;
+    SrkChunkPlan& pl = h->plan;
+    pl.P = 0;
+    pl.child = nullptr;
+    for (DevBuf& b : h->plan_bufs) dev_free(b);
+    h->plan_bufs.clear();
+    h->plan_children.clear();
+    if (!h->use_envelope || !h->use_chunks) return SRK_OK;
+    int64_t maxdist = 0;
+    for (int32_t j = 0; j < d.M; ++j) maxdist = std::max<int64_t>(maxdist, 10 * (int64_t)(j - h->min_cv[(size_t)j]) + 9);
+    int64_t sepw = maxdist <= 256 ? 256 : (maxdist <= 512 ? 512 : 0);
+    if (sepw == 0) return SRK_OK;
+    return make_plan(h, pl, d.ld, sepw, SRK_CHOL_NB, h->row_end_h, h->col_begin_h);
 }
 
 // Skyline of the RCS from the covisibility (min_cv[j] = smallest frame index sharing a landmark with frame j).

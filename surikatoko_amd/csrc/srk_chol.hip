@@ -951,8 +951,12 @@ void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, c
     for (int parity = 0; parity < 2; ++parity)
         hipLaunchKernelGGL(k_sep_reduce, dim3((unsigned)(2 * sepw), 1, (unsigned)((P + 1) / 2)), dim3(256), 0, s, B, parity,
                            P, sepw, pl.Cs, lds, pl.ws);
-    chol_factor(s, Bs, 1, &Hs, d_info, nullptr);
-    chol_bwd(s, Bs, 1, &Hs);
+    if (pl.child) { // the separator system is block tridiagonal: chunk it again
+        srk_chol_solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info);
+    } else {
+        chol_factor(s, Bs, 1, &Hs, d_info, nullptr);
+        chol_bwd(s, Bs, 1, &Hs);
+    }
     hipLaunchKernelGGL(k_sep_scatter, dim3((unsigned)((lds + 255) / 256)), dim3(256), 0, s, lds, sepw, pl.d_sep_start,
                        pl.xs, x);
     hipLaunchKernelGGL(k_bwd_border, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);

@@ -102,6 +102,8 @@ struct SrkChunkPlan {
     double *Cs = nullptr, *ws = nullptr, *ys = nullptr, *xs = nullptr, *dinvs = nullptr;
     std::vector<int64_t> s_row_end, s_col_begin;
     int64_t* d_sep_start = nullptr;  // device: first global variable of separator c
+    int64_t* d_sep_env = nullptr;    // device: skyline (first column per 128-row tile) of the separator system
+    SrkChunkPlan* child = nullptr;   // plan of the separator system itself (nested dissection); NULL = direct solve
 };
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
                             double* x, const int64_t* d_env_col, int* d_info);
