@@ -594,9 +594,11 @@ void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* 
 #define SRK_GRP_MAXNF 24     // nf (nf + 1) half blocks <= SRK_GRP_THREADS * 2
 #define SRK_GRP_NF1 21       // nf (nf + 1) <= SRK_GRP_THREADS: one half block per thread
 #define SRK_GRP_MAXPTS 128
+#ifndef SRK_GRP_PB
 #define SRK_GRP_PB 4         // landmarks staged per barrier round
+#endif
 #define SRK_GRP_WS 36        // LDS doubles per (landmark, frame) of W: 3 x (5 | pad | 5 | pad), halves 16-byte aligned
-#define SRK_GRP_PRE 6        // prefetch registers: PB * MAXNF * 30 / THREADS, rounded up
+#define SRK_GRP_PRE ((30 * SRK_GRP_PB * SRK_GRP_MAXNF + SRK_GRP_THREADS - 1) / SRK_GRP_THREADS) // prefetch registers
 static_assert(SRK_GRP_MAXNF == SRK_GRP_MAXNF_HOST && SRK_GRP_NF1 == SRK_GRP_NF1_HOST && SRK_GRP_MAXPTS == SRK_GRP_MAXPTS_HOST,
               "host / kernel grouping constants differ");
 static_assert(SRK_GRP_PRE * SRK_GRP_THREADS >= 30 * SRK_GRP_PB * SRK_GRP_MAXNF, "staging map too small");
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         goff[j] = in ? q : 0;
         loff[j] = in ? pl * W_LM + a * SRK_GRP_WS + 12 * m + r + (r >= 5) : 0;
         // W row k, folded into the 64-bit base below to keep the per-round address a single add
-        goff[j] |= (in ? k : 0) << 16; // q < PB * MAXNF = 96 < 65536
+        goff[j] |= (in ? k : 0) << 16; // q < PB * MAXNF < 65536
     }
     double pre[SRK_GRP_PRE];
     auto prefetch = [&](int pb) {

@@ -846,7 +846,9 @@ __global__ __launch_bounds__(256) void k_chunk_gather(const double* __restrict__
     if (threadIdx.x == 0) wc[i] = 0.0;
 }
 
-// separator system: Cs (lds x lds) block diagonal part from S, ws from rhs
+// separator system: Cs (lds x lds) block diagonal part from S, ws from rhs.  Only the block tridiagonal band is ever
+// written by the factorisation (and read by a child plan's gather); everything outside it stays the zero it was
+// allocated with.
 __global__ __launch_bounds__(256) void k_sep_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
                                                     const int64_t* __restrict__ sep_start, int64_t sepw,
                                                     double* __restrict__ Cs, int64_t lds, double* __restrict__ ws)
@@ -855,7 +857,8 @@ __global__ __launch_bounds__(256) void k_sep_gather(const double* __restrict__ S
     const int64_t c = i / sepw, u = i - c * sepw;
     const int64_t g = sep_start[c] + u;
     double* dst = Cs + i * lds;
-    for (int64_t j = threadIdx.x; j < lds; j += 256) {
+    const int64_t j0 = c > 0 ? (c - 1) * sepw : 0, j1 = (c + 1) * sepw; // lower part of the band
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
         int64_t cj = j / sepw, v = j - cj * sepw;
         dst[j] = (cj == c && v <= u) ? S[g * ld + sep_start[c] + v] : 0.0;
     }
@@ -894,26 +897,31 @@ __global__ __launch_bounds__(256) void k_sep_scatter(int64_t n, int64_t sepw, co
     if (i < n) x[sep_start[i / sepw] + i % sepw] = xs[i];
 }
 
-// border part of a chunk's solution = the separator solution; fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i]
+// border part of a chunk's solution = the separator solution; fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i].
+// A workgroup takes 64 columns; its four waves split the 2 sepw border rows and combine through LDS.
 __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs)
 {
     __shared__ double sx[1024];
+    __shared__ double sp[4][64];
     const int c = blockIdx.z;
     const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;
-    if ((int64_t)blockIdx.x * 256 >= nc) return;
+    if ((int64_t)blockIdx.x * 64 >= nc) return;
     const int64_t top_sep = c > 0 ? c - 1 : -1, bot_sep = c < P - 1 ? c : -1;
     for (int64_t u2 = threadIdx.x; u2 < 2 * sepw; u2 += 256) {
         const int64_t su = u2 < sepw ? top_sep : bot_sep;
         sx[u2] = su < 0 ? 0.0 : xs[su * sepw + (u2 < sepw ? u2 : u2 - sepw)];
     }
     __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= nc) return;
-    const double* col = B.it[c].A + nc * ldc + j;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane; // nc is a multiple of 64
+    const int64_t rows = (2 * sepw) / 4, u0 = wave * rows;
+    const double* col = B.it[c].A + (nc + u0) * ldc + j;
     double acc = 0;
 #pragma unroll 8
-    for (int64_t u2 = 0; u2 < 2 * sepw; ++u2) acc += col[u2 * ldc] * sx[u2];
-    B.it[c].y[j] -= acc;
+    for (int64_t u2 = 0; u2 < rows; ++u2) acc = fma(col[u2 * ldc], sx[u0 + u2], acc);
+    sp[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) B.it[c].y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
 // interior part of the global solution
@@ -923,8 +931,8 @@ __global__ __launch_bounds__(256) void k_chunk_scatter(const CholBatch B, const 
     if (j < B.it[blockIdx.z].ncols) x[first.v[blockIdx.z] + j] = B.it[blockIdx.z].x[j];
 }
 
-void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
-                            double* x, const int64_t* d_env_col, int* d_info)
+static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs, double* x,
+                          const int64_t* d_env_col, int* d_info)
 {
     const int P = pl.P;
     const int64_t sepw = pl.sepw, lds = pl.lds;
@@ -952,15 +960,21 @@ void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, c
         hipLaunchKernelGGL(k_sep_reduce, dim3((unsigned)(2 * sepw), 1, (unsigned)((P + 1) / 2)), dim3(256), 0, s, B, parity,
                            P, sepw, pl.Cs, lds, pl.ws);
     if (pl.child) { // the separator system is block tridiagonal: chunk it again
-        srk_chol_solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info);
+        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info);
     } else {
         chol_factor(s, Bs, 1, &Hs, d_info, nullptr);
         chol_bwd(s, Bs, 1, &Hs);
     }
     hipLaunchKernelGGL(k_sep_scatter, dim3((unsigned)((lds + 255) / 256)), dim3(256), 0, s, lds, sepw, pl.d_sep_start,
                        pl.xs, x);
-    hipLaunchKernelGGL(k_bwd_border, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
+    hipLaunchKernelGGL(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
     chol_bwd(s, B, P, H);
     hipLaunchKernelGGL(k_chunk_scatter, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, first, x);
+}
+
+void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
+                            double* x, const int64_t* d_env_col, int* d_info)
+{
+    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info);
     hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }
