@@ -42,12 +42,13 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(N, M, O, ld):
-    """SURVEY 8(d) per-call algorithmic bytes (fp64)."""
+def algorithmic_bytes(N, M, O, ld, rcs_fill=1.0):
+    """SURVEY 8(d) per-call algorithmic bytes (fp64).  The reduced camera system counts only the entries inside the
+    covisibility skyline (rcs_fill = 1 when it is treated as dense)."""
     k2 = O * (4 + 16) + (N + 1) * 8 + N * 24 + M * (72 + 24 + 72) + O * 240 + N * (72 + 24) + M * (800 + 80)
     k1 = O * 20 + (N + 1) * 8 + N * 24 + M * 168 + 8
     n = 10 * M - 7
-    k3 = O * 240 + N * 96 + n * n * 8
+    k3 = O * 240 + N * 96 + int(rcs_fill * n * n * 8)
     k5 = O * 240 + N * (72 + 24 + 24) + M * 80
     k4_flops = n ** 3 / 3.0
     return dict(jacobian=k2, error=k1, schur=k3, backsub=k5, solve_flops=k4_flops, solve_bytes=n * n * 8)
@@ -136,7 +137,7 @@ def main():
     for _ in range(args.warmup):
         step()
     acc = {k: 0.0 for k in ("ms_jacobian", "ms_schur", "ms_solve", "ms_backsub", "ms_apply", "ms_error",
-                            "ms_jacobian_kernel", "ms_solve_syrk")}
+                            "ms_jacobian_kernel", "ms_solve_syrk", "solve_mfma_flops")}
     attempts = 0
     iterations = 0
     barrier()
@@ -162,11 +163,10 @@ def main():
     chain_probe = None
     if world == 1 and args.rcs != "dense" and not args.no_dense_probe:
         ba.set_rcs_mode(0)
-        dflops = ba.solve_mfma_flops()
         step()
         r = step()
         dense_probe = {"ms_solve": r.ms_solve / max(r.attempts, 1), "ms_trail": r.ms_solve_syrk / max(r.attempts, 1),
-                       "flops": dflops}
+                       "flops": r.solve_mfma_flops / max(r.attempts, 1)}
         if rcs_chunks >= 2:  # the same skyline factorised as ONE panel chain, for the chunking gain
             ba.set_rcs_mode(1)
             step()
@@ -179,7 +179,7 @@ def main():
         K = max(args.steps, 1)
         ms_per_step = 1e3 * dt / K
         ld = ((10 * M + 63) // 64) * 64
-        ab = algorithmic_bytes(shard.N, M, shard.O, ld)
+        ab = algorithmic_bytes(shard.N, M, shard.O, ld, rcs_fill)
         per_it = {k: v / K for k, v in acc.items()}
         per_attempt = {k: v / max(attempts, 1) for k, v in acc.items()}
 
@@ -211,12 +211,9 @@ def main():
             "error_phase": hbm(ab["error"], per_attempt["ms_error"], "k_error"),
         }
         ms_syrk = per_attempt["ms_solve_syrk"]
-        chunked = rcs_chunks >= 2 and args.rcs == "chunks"
-        if chunked:
-            # chunks factorise concurrently on their own streams: there is no per-launch event pair to sum, so the MFMA
-            # rate is priced against the WHOLE solve phase (a lower bound of the trailing-update kernels' own rate)
-            ms_syrk = per_attempt["ms_solve"]
-        # flops actually executed by the MFMA trailing-update launches (= n^3/3 up to blocking when dense)
+        # flops actually executed by the MFMA trailing-update launches (= n^3/3 up to blocking when dense), counted by
+        # the library while it issues them; their time is the sum of the HIP event pairs around those launches
+        mfma_flops = per_attempt["solve_mfma_flops"]
         tf = mfma_flops / (ms_syrk * 1e-3) / 1e12 if ms_syrk > 0 else 0.0
         kernels["solve_syrk_mfma"] = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS,
                                       "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -236,9 +233,10 @@ def main():
                 "algorithmic_flops": dense_probe["flops"], "ms_solve_phase": dense_probe["ms_solve"],
                 "note": "one untimed step with the reduced camera system forced dense (--rcs dense gives the same)"}
         kernels["solve_panel_chain"] = {
-            "bound": "latency", "ms": per_attempt["ms_solve"] - (0.0 if chunked else per_attempt["ms_solve_syrk"]),
-            "note": "sequential 64-column panel kernels + backward substitution of the blocked Cholesky: a dependency "
-                    "chain of n pivots, bound by per-pivot latency, not by HBM or MFMA throughput"}
+            "bound": "latency", "ms": per_attempt["ms_solve"] - per_attempt["ms_solve_syrk"],
+            "note": "64-column panel kernels + backward substitution of the blocked Cholesky (+ gather / reduce / "
+                    "scatter of the nested-dissection levels): a dependency chain of pivots, bound by per-pivot "
+                    "latency, not by HBM or MFMA throughput"}
         # dominant kernel = the phase with the largest share of the step
         shares = {"jacobian_phase": per_it["ms_jacobian"], "schur_phase": per_it["ms_schur"],
                   "solve_syrk_mfma": per_it["ms_solve"], "backsub_phase": per_it["ms_backsub"]}

@@ -72,7 +72,8 @@ typedef struct srk_ba_report {
     double ms_total;         /* wall time of the optimise call */
     int64_t schur_launches, jacobian_launches; /* kernel launches of the two HBM-bound phases */
     double ms_jacobian_kernel; /* time of the point-major Jacobian kernel alone (roofline numerator) */
-    double ms_solve_syrk;      /* time inside the MFMA trailing-update kernels of the dense solve */
+    double ms_solve_syrk;      /* time inside the MFMA trailing-update kernels of the solve (srk_ba_set_profile) */
+    double solve_mfma_flops;   /* flops those launches executed, summed over the call (srk_ba_set_profile) */
 } srk_ba_report;
 
 typedef struct srk_ba_normalizer {
@@ -171,7 +172,7 @@ int srk_ba_set_rcs_mode(srk_ba*, int mode /* 0 = dense lower triangle, 1 = skyli
                                               2 = skyline cut into independent chunks + separator system (default) */);
 int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one chain) */
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
-double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current skyline) */
+double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current mode / plan) */
 
 /* bench knob: record event pairs around every MFMA trailing-update launch (fills report.ms_solve_syrk) */
 int srk_ba_set_profile(srk_ba*, int profile_syrk);

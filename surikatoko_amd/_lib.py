@@ -29,7 +29,8 @@ class Report(C.Structure):
                 ("ms_jacobian", C.c_double), ("ms_schur", C.c_double), ("ms_solve", C.c_double),
                 ("ms_backsub", C.c_double), ("ms_apply", C.c_double), ("ms_error", C.c_double),
                 ("ms_total", C.c_double), ("schur_launches", C.c_int64), ("jacobian_launches", C.c_int64),
-                ("ms_jacobian_kernel", C.c_double), ("ms_solve_syrk", C.c_double)]
+                ("ms_jacobian_kernel", C.c_double), ("ms_solve_syrk", C.c_double),
+                ("solve_mfma_flops", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

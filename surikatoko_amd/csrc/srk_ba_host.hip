@@ -73,6 +73,7 @@ struct srk_ba {
     // timing
     hipEvent_t ev[16]{};
     std::vector<hipEvent_t> chol_ev;
+    SrkSolveProf solve_prof; // event pairs / flops of the last profiled solve
     bool profile_syrk = false;
     double last_hessian_factor = 0;
 };
@@ -817,28 +818,34 @@ static int phase_schur(srk_ba* h, double c)
     return SRK_OK;
 }
 
+// one solve of the reduced camera system in the current mode; prof may be NULL
+static void launch_solve(srk_ba* h, SrkSolveProf* prof)
+{
+    const SrkDims& d = h->d;
+    if (h->plan.P >= 2)
+        srk_chol_solve_chunked(h->stream, h->plan, d.ld, P<double>(h->S), P<double>(h->rhs), P<double>(h->dc),
+                               P<int64_t>(h->env_col), P<int>(h->info), prof);
+    else
+        srk_chol_solve(h->stream, d.ld, P<double>(h->S), P<double>(h->rhs), P<double>(h->wy), P<double>(h->dc),
+                       P<int>(h->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->dinv), prof);
+}
+
 static int phase_solve(srk_ba* h, bool profile)
 {
     const SrkDims& d = h->d;
-    hipStream_t s = h->stream;
-    HIPCHK(h, hipMemsetAsync(h->info.p, 0, 4, s));
-    hipEvent_t* evs = nullptr;
-    if (profile && h->plan.P < 2) { // per-panel event pairs exist on the single-chain path only
-        size_t need = (size_t)(2 * (d.ld / SRK_CHOL_NB));
+    HIPCHK(h, hipMemsetAsync(h->info.p, 0, 4, h->stream));
+    h->solve_prof = SrkSolveProf{};
+    if (profile) {
+        size_t need = (size_t)(2 * (2 * (d.ld / SRK_CHOL_NB) + 64)); // every level of a nested plan included
         while (h->chol_ev.size() < need) {
             hipEvent_t e;
             HIPCHK(h, hipEventCreate(&e));
             h->chol_ev.push_back(e);
         }
-        evs = h->chol_ev.data();
+        h->solve_prof.ev = h->chol_ev.data();
+        h->solve_prof.cap = h->chol_ev.size();
     }
-    double* wy = P<double>(h->wy);
-    if (h->plan.P >= 2)
-        srk_chol_solve_chunked(s, h->plan, d.ld, P<double>(h->S), P<double>(h->rhs), P<double>(h->dc),
-                               P<int64_t>(h->env_col), P<int>(h->info));
-    else
-        srk_chol_solve(s, d.ld, P<double>(h->S), P<double>(h->rhs), wy, P<double>(h->dc), P<int>(h->info),
-                       h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->dinv), evs);
+    launch_solve(h, profile ? &h->solve_prof : nullptr);
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
@@ -1040,13 +1047,13 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->ms_apply += ev_ms(5, 6);
             rep->ms_error += ev_ms(6, 7);
             rep->schur_launches += 2;
-            if (h->profile_syrk && h->plan.P < 2) {
-                int64_t nblk = d.ld / SRK_CHOL_NB;
-                for (int64_t kb = 0; kb < nblk; ++kb) {
+            if (h->profile_syrk) {
+                for (size_t kb = 0; kb < h->solve_prof.n; ++kb) {
                     float ms = 0;
-                    if (hipEventElapsedTime(&ms, h->chol_ev[(size_t)(2 * kb)], h->chol_ev[(size_t)(2 * kb + 1)]) == hipSuccess)
+                    if (hipEventElapsedTime(&ms, h->chol_ev[2 * kb], h->chol_ev[2 * kb + 1]) == hipSuccess)
                         rep->ms_solve_syrk += ms;
                 }
+                rep->solve_mfma_flops += h->solve_prof.flops;
             }
             if (back.info != 0 || info2 != 0) { decrease = 2; break; } // solve failed (:807-808, :1912-1913, :1953-1954)
             err_new = back.err;
@@ -1310,13 +1317,10 @@ double srk_ba_rcs_fill(srk_ba* h)
 double srk_ba_solve_mfma_flops(srk_ba* h)
 {
     if (!h || !h->have_scene) return -1.0;
-    double f = 0;
-    const int64_t nk = h->d.ld / SRK_CHOL_NB;
-    for (int64_t K = 0; K < nk; ++K) {
-        int64_t T = (h->row_end_h[(size_t)K] - SRK_CHOL_NB * (K + 1)) / 128;
-        if (T > 0) f += (double)(T * (T + 1) / 2) * 128.0 * 128.0 * (double)SRK_CHOL_NB * 2.0;
-    }
-    return f;
+    SrkSolveProf dry;
+    dry.dry = true; // walks the launch sequence of the current mode without launching anything
+    launch_solve(h, &dry);
+    return dry.flops;
 }
 
 // knob for bench.py: event pairs around every MFMA trailing-update launch (report.ms_solve_syrk)

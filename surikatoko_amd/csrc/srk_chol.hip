@@ -694,12 +694,15 @@ __global__ __launch_bounds__(256) void k_check_finite(int64_t n, const double* _
 }
 
 // ---------------------------------------------------------------- host drivers
+// SrkSolveProf (optional): event pairs around every MFMA trailing-update launch and the flops those launches execute;
+// in `dry` mode nothing is launched and only the flops are counted.
+#define LAUNCH(...) do { if (!(prof && prof->dry)) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // chol_factor: for every item of the batch, eliminate its first `ncols` columns (multiple of 256).  Rows taking part
 // in outer panel K are the skyline rows [256 K, row_end[K]) (clipped to ncols) plus the border rows
 // [r2_begin, r2_end) (multiples of 128; empty when r2_begin == r2_end).  The forward substitution of w rides along
 // (k_panel); y receives L^-1 w for the eliminated columns, the border part of w its Schur-complement update.
 // Items advance in lock step: launch K serves outer panel K of every item that has one.
-static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, int* d_info, hipEvent_t* ev_pairs)
+static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, int* d_info, SrkSolveProf* prof)
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
@@ -727,40 +730,45 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
                 if (rows > 0) blocks = std::max(blocks, (rows + PANEL_ROWS - 1) / PANEL_ROWS);
                 tiles = std::max(tiles, rows1 / NB + rows2 / NB);
             }
-            hipLaunchKernelGGL(k_panel, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, st, d, d_info);
+            LAUNCH(k_panel, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, st, d, d_info);
             const int64_t c_hi = K * (NBO / NB) + (NBO / NB - 1);
             if (jsub < NBO / NB - 1 && tiles > 0)
-                hipLaunchKernelGGL(k_upd64, dim3((unsigned)tiles, (unsigned)(c_hi - d), (unsigned)n), dim3(256), 0, s, B,
+                LAUNCH(k_upd64, dim3((unsigned)tiles, (unsigned)(c_hi - d), (unsigned)n), dim3(256), 0, s, B,
                                    st, d, c_hi);
         }
         const int64_t c_first = k0 + NBO;
         int64_t T = 0;
+        double flops = 0;
         for (int i = 0; i < n; ++i) {
             if (st.v[i] < 0) continue;
             int64_t T1 = (st.v[i] - c_first) / TL;
             if (T1 < 0) T1 = 0;
-            T = std::max(T, T1 + (B.it[i].r2_end - B.it[i].r2_begin) / TL);
+            const int64_t Ti = T1 + (B.it[i].r2_end - B.it[i].r2_begin) / TL;
+            T = std::max(T, Ti);
+            flops += (double)(Ti * (Ti + 1) / 2) * (double)TL * (double)TL * (double)NBO * 2.0;
         }
-        if (ev_pairs) hipEventRecord(ev_pairs[2 * K], s);
+        const bool timed = prof && !prof->dry && T > 0 && 2 * prof->n + 1 < prof->cap;
+        if (prof && T > 0) prof->flops += flops;
+        if (timed) hipEventRecord(prof->ev[2 * prof->n], s);
         if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
             const int64_t T64 = 2 * T;
-            hipLaunchKernelGGL(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
+            LAUNCH(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
                                c_first);
         } else if (T > 0) {
-            hipLaunchKernelGGL(k_trail, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
+            LAUNCH(k_trail, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
                                c_first);
         }
-        if (ev_pairs) hipEventRecord(ev_pairs[2 * K + 1], s);
+        if (timed) hipEventRecord(prof->ev[2 * prof->n + 1], s), ++prof->n;
     }
 }
 
 // chol_bwd: x = L^-T y over the first `ncols` columns of every item (the border part, if any, has been folded into y
 // already).  Launch t serves outer panel nout_i - 1 - t of item i.
-static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H)
+static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, SrkSolveProf* prof)
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
-    hipLaunchKernelGGL(k_dinv, dim3((unsigned)(nout * (NBO / NB)), 1, (unsigned)n), dim3(256), 0, s, B);
+    LAUNCH(k_dinv, dim3((unsigned)(nout * (NBO / NB)), 1, (unsigned)n), dim3(256), 0, s, B);
     for (int64_t t = 0; t < nout; ++t) {
         CholStep Kst, cbeg;
         int64_t blocks = 1;
@@ -778,7 +786,7 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
             Kst.v[i] = K;
             cbeg.v[i] = cb;
         }
-        hipLaunchKernelGGL(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg);
+        LAUNCH(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg);
     }
 }
 
@@ -786,16 +794,15 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
 // row_end[K] (host, one per outer panel, multiple of 128): rows >= row_end[K] have no non-zero in the panel's
 // columns and are skipped; NULL = dense.  col_begin[d64] (host, per 64-tile, may be NULL): first column with a
 // non-zero in tile row d64.  dinv: scratch, (ld / 64) * 64 * 64 doubles (inverses of the diagonal tiles).
-// ev_pairs: optional 2 events per outer panel around the trailing update.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
-                    const int64_t* row_end, const int64_t* col_begin, double* dinv, hipEvent_t* ev_pairs)
+                    const int64_t* row_end, const int64_t* col_begin, double* dinv, SrkSolveProf* prof)
 {
     CholBatch B{};
     B.it[0] = CholItem{ A, w, y, x, dinv, ld, ld, ld, ld };
     CholHostItem H{ row_end, col_begin };
-    chol_factor(s, B, 1, &H, d_info, ev_pairs);
-    chol_bwd(s, B, 1, &H);
-    hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
+    chol_factor(s, B, 1, &H, d_info, prof);
+    chol_bwd(s, B, 1, &H, prof);
+    LAUNCH(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }
 
 // ================================================================ chunked (bordered block-diagonal) solve
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(256) void k_chunk_scatter(const CholBatch B, const 
 }
 
 static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs, double* x,
-                          const int64_t* d_env_col, int* d_info)
+                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof)
 {
     const int P = pl.P;
     const int64_t sepw = pl.sepw, lds = pl.lds;
@@ -951,30 +958,30 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
     Bs.it[0] = CholItem{ pl.Cs, pl.ws, pl.ys, pl.xs, pl.dinvs, lds, lds, lds, lds };
     const unsigned cblocks = (unsigned)((max_nc + 255) / 256);
 
-    hipLaunchKernelGGL(k_chunk_gather, dim3((unsigned)max_ldc, 1, (unsigned)P), dim3(256), 0, s, S, ld, rhs, d_env_col, B,
+    LAUNCH(k_chunk_gather, dim3((unsigned)max_ldc, 1, (unsigned)P), dim3(256), 0, s, S, ld, rhs, d_env_col, B,
                        first, sepw, P);
-    hipLaunchKernelGGL(k_sep_gather, dim3((unsigned)lds), dim3(256), 0, s, S, ld, rhs, pl.d_sep_start, sepw, pl.Cs, lds,
+    LAUNCH(k_sep_gather, dim3((unsigned)lds), dim3(256), 0, s, S, ld, rhs, pl.d_sep_start, sepw, pl.Cs, lds,
                        pl.ws);
-    chol_factor(s, B, P, H, d_info, nullptr);
+    chol_factor(s, B, P, H, d_info, prof);
     for (int parity = 0; parity < 2; ++parity)
-        hipLaunchKernelGGL(k_sep_reduce, dim3((unsigned)(2 * sepw), 1, (unsigned)((P + 1) / 2)), dim3(256), 0, s, B, parity,
+        LAUNCH(k_sep_reduce, dim3((unsigned)(2 * sepw), 1, (unsigned)((P + 1) / 2)), dim3(256), 0, s, B, parity,
                            P, sepw, pl.Cs, lds, pl.ws);
     if (pl.child) { // the separator system is block tridiagonal: chunk it again
-        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info);
+        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof);
     } else {
-        chol_factor(s, Bs, 1, &Hs, d_info, nullptr);
-        chol_bwd(s, Bs, 1, &Hs);
+        chol_factor(s, Bs, 1, &Hs, d_info, prof);
+        chol_bwd(s, Bs, 1, &Hs, prof);
     }
-    hipLaunchKernelGGL(k_sep_scatter, dim3((unsigned)((lds + 255) / 256)), dim3(256), 0, s, lds, sepw, pl.d_sep_start,
+    LAUNCH(k_sep_scatter, dim3((unsigned)((lds + 255) / 256)), dim3(256), 0, s, lds, sepw, pl.d_sep_start,
                        pl.xs, x);
-    hipLaunchKernelGGL(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
-    chol_bwd(s, B, P, H);
-    hipLaunchKernelGGL(k_chunk_scatter, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, first, x);
+    LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
+    chol_bwd(s, B, P, H, prof);
+    LAUNCH(k_chunk_scatter, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, first, x);
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
-                            double* x, const int64_t* d_env_col, int* d_info)
+                            double* x, const int64_t* d_env_col, int* d_info, SrkSolveProf* prof)
 {
-    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info);
-    hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
+    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof);
+    LAUNCH(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
 }

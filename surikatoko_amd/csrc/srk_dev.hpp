@@ -74,6 +74,15 @@ void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, doub
 void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
                          double* packed, int dir);
 
+// optional profile of one solve: event pairs around every MFMA trailing-update launch (n pairs recorded, at most
+// cap / 2) and the flops those launches execute; dry = count only, launch nothing
+struct SrkSolveProf {
+    hipEvent_t* ev = nullptr;
+    size_t cap = 0, n = 0;
+    double flops = 0;
+    bool dry = false;
+};
+
 // ---- dense SPD solver (srk_chol.hip) ----
 // In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) with the forward
 // substitution folded in, then the backward substitution.  w: rhs (destroyed), y: scratch, x: solution.
@@ -81,7 +90,7 @@ void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, cons
 // row_end / col_begin: optional host arrays describing the skyline of A (see srk_chol.hip); NULL = dense.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
                     const int64_t* row_end, const int64_t* col_begin, double* dinv /* (ld / 64) * 4096 doubles */,
-                    hipEvent_t* ev_pairs /* 2 * (ld / SRK_CHOL_NB) events or NULL */);
+                    struct SrkSolveProf* prof /* may be NULL */);
 
 // ---- chunked (bordered block-diagonal) solve of a banded reduced camera system (srk_chol.hip) ----
 #include <vector>
@@ -106,4 +115,4 @@ struct SrkChunkPlan {
     SrkChunkPlan* child = nullptr;   // plan of the separator system itself (nested dissection); NULL = direct solve
 };
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
-                            double* x, const int64_t* d_env_col, int* d_info);
+                            double* x, const int64_t* d_env_col, int* d_info, struct SrkSolveProf* prof /* may be NULL */);

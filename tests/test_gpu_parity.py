@@ -447,3 +447,27 @@ def test_chunked_end_to_end_matches_single_chain(gpu):
     assert res[2][2] == pytest.approx(res[1][2], rel=1e-8)
     assert np.abs(res[2][3].points - res[1][3].points).max() < 1e-8
     assert np.abs(res[2][3].cam_T - res[1][3].cam_T).max() < 1e-8
+
+
+def test_nested_plan_counts_its_mfma_flops(gpu):
+    """srk_ba_solve_mfma_flops (dry walk of the launch sequence) == the flops the profiled solve reports, in every
+    reduced-camera-system mode; nested dissection executes more trailing-update flops than the single chain."""
+    spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
+    sc = sa.generate_scene(spec)
+    gpu.set_profile(True)
+    flops = {}
+    try:
+        for mode in (0, 1, 2):
+            gpu.set_rcs_mode(mode)
+            s2 = sc.copy()
+            gpu.ComputeInplace(spec.f0, s2, None, 1)
+            r = gpu.report
+            assert r.attempts >= 1
+            assert r.solve_mfma_flops / r.attempts == pytest.approx(gpu.solve_mfma_flops(), rel=1e-12)
+            assert r.ms_solve_syrk > 0
+            flops[mode] = gpu.solve_mfma_flops()
+    finally:
+        gpu.set_profile(False)
+        gpu.set_rcs_mode(2)
+    assert gpu.rcs_chunks() >= 2
+    assert flops[0] > flops[1] > 0

@@ -5,6 +5,7 @@ MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes
 -> doubled here; WRITE_SIZE is exact for 16-B/lane streaming stores and float atomics.  rocprofv3 reports both in
 units of 1 KiB? -> we read the raw counter value column and print bytes = value * 1024 (guide section 7)."""
 import csv
+import re
 import glob
 import sys
 from collections import defaultdict
@@ -14,7 +15,7 @@ def load(d):
     acc = defaultdict(lambda: [0.0, 0])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0]
+            name = re.sub(r"<.*>$", "", re.sub(r"^void ", "", r["Kernel_Name"].split("(")[0]))
             acc[name][0] += float(r["Counter_Value"])
             acc[name][1] += 1
     return acc
