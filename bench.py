@@ -108,7 +108,7 @@ def main():
         shard, (lo, hi) = scene, (0, scene.N)
 
     ba = sa.BundleAdjustmentKanatani(local_rank)
-    ba.set_profile(True)
+    ba.set_profile(0)  # the timed region carries no instrumentation; phases are timed in separate steps below
     if world > 1:
         from surikatoko_amd.dist import make_allreduce_hook
         ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
@@ -136,18 +136,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    acc = {k: 0.0 for k in ("ms_jacobian", "ms_schur", "ms_solve", "ms_backsub", "ms_apply", "ms_error",
-                            "ms_jacobian_kernel", "ms_solve_syrk", "solve_mfma_flops")}
-    attempts = 0
     iterations = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        r = step()
-        for k in acc:
-            acc[k] += getattr(r, k)
-        attempts += r.attempts
-        iterations += r.iterations
+        iterations += step().iterations
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -156,6 +149,21 @@ def main():
         dt = float(t.item())
     err_final = ba.report.err_final
     err_initial = ba.report.err_initial
+
+    # outside the timed region: the same steps again with the library's HIP-event instrumentation on (one event pair
+    # per phase, one per MFMA trailing-update launch) -- every event costs a few microseconds on the stream, so the
+    # phase times below add up to slightly more than ms_per_step
+    ba.set_profile(2)
+    acc = {k: 0.0 for k in ("ms_jacobian", "ms_schur", "ms_solve", "ms_backsub", "ms_apply", "ms_error",
+                            "ms_jacobian_kernel", "ms_solve_syrk", "solve_mfma_flops")}
+    attempts = 0
+    prof_steps = max(1, min(args.steps, 10))
+    step()
+    for _ in range(prof_steps):
+        r = step()
+        for k in acc:
+            acc[k] += getattr(r, k)
+        attempts += r.attempts
 
     # outside the timed region: one more step with the reduced camera system treated as DENSE, so that every bench
     # line carries the fp64-MFMA trailing update at full size (the north-star's "dense RCS GEMM" evidence)
@@ -180,7 +188,7 @@ def main():
         ms_per_step = 1e3 * dt / K
         ld = ((10 * M + 63) // 64) * 64
         ab = algorithmic_bytes(shard.N, M, shard.O, ld, rcs_fill)
-        per_it = {k: v / K for k, v in acc.items()}
+        per_it = {k: v / prof_steps for k, v in acc.items()}
         per_attempt = {k: v / max(attempts, 1) for k, v in acc.items()}
 
         # HBM traffic per launch from the committed PMC passes of this configuration (profiles/, rocprofv3 --pmc in
@@ -262,7 +270,8 @@ def main():
                        "parallelism": f"landmark shards x{world}" if world > 1 else "single GPU",
                        "points_per_rank": shard.N, "obs_per_rank": shard.O, "rcs_dim": 10 * M - 7,
                        "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks},
-            "attempts_per_iteration": attempts / max(iterations, 1),
+            "attempts_per_iteration": attempts / prof_steps,
+            "profiled_steps": prof_steps,
             "ms_per_iter": {"jacobian": per_it["ms_jacobian"], "schur": per_it["ms_schur"],
                             "solve": per_it["ms_solve"], "backsub": per_it["ms_backsub"],
                             "apply": per_it["ms_apply"], "error": per_it["ms_error"]},

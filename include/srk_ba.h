@@ -174,8 +174,11 @@ int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
 double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current mode / plan) */
 
-/* bench knob: record event pairs around every MFMA trailing-update launch (fills report.ms_solve_syrk) */
-int srk_ba_set_profile(srk_ba*, int profile_syrk);
+/* device-time instrumentation of srk_ba_optimize / srk_ba_compute_inplace: 0 = none (report.ms_* stay 0 except
+ * ms_total), 1 = one HIP event pair per phase (default; fills report.ms_*), 2 = additionally event pairs around
+ * every MFMA trailing-update launch (fills report.ms_solve_syrk / solve_mfma_flops).  Every event costs a few
+ * microseconds on the stream. */
+int srk_ba_set_profile(srk_ba*, int level);
 
 /* dense SPD solve A x = b on the device (the reduced-camera-system solver on its own; A row-major
  * n x n, lower triangle read).  returns 0 ok, 1 not positive definite, negative on error. */

@@ -240,8 +240,11 @@ class BundleAdjustmentKanatani:
     def reset(self):
         self._raise(self._lib.srk_ba_reset_scene(C.c_void_p(self._h)))
 
-    def set_profile(self, on=True):
-        self._raise(self._lib.srk_ba_set_profile(C.c_void_p(self._h), C.c_int(int(on))))
+    def set_profile(self, level=2):
+        """0 = no device events, 1 = per-phase events (default of the library), 2 / True = + MFMA update events."""
+        if level is True:
+            level = 2
+        self._raise(self._lib.srk_ba_set_profile(C.c_void_p(self._h), C.c_int(int(level))))
 
     def set_covisibility(self, min_cv):
         """Global covisibility for sharded runs (see covisibility()); None = dense."""

@@ -74,7 +74,8 @@ struct srk_ba {
     hipEvent_t ev[16]{};
     std::vector<hipEvent_t> chol_ev;
     SrkSolveProf solve_prof; // event pairs / flops of the last profiled solve
-    bool profile_syrk = false;
+    int profile_level = 1; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
+    double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
     double last_hessian_factor = 0;
 };
 
@@ -142,6 +143,10 @@ srk_ba* srk_ba_create(int device_id)
             delete h;
             return nullptr;
         }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_back), 64, hipHostMallocDefault) != hipSuccess) {
+        delete h;
+        return nullptr;
+    }
     return h;
 }
 
@@ -160,6 +165,7 @@ void srk_ba_destroy(srk_ba* h)
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : h->chol_ev) hipEventDestroy(e);
+    if (h->host_back) hipHostFree(h->host_back);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -748,15 +754,20 @@ static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
     return SRK_OK;
 }
 
-static int phase_error(srk_ba* h, int which, double* err_host)
+// with_status: {solver info, point-update finite flag (lives behind acc)} are packed next to the error scalar and
+// summed over the ranks with it, so every rank takes the same accept / reject decision
+static int phase_error(srk_ba* h, int which, double* err_host, bool with_status = false)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
     int32_t np = srk_error_partials(d);
     srk_launch_error(s, d, P<double>(h->pts[which]), P<double>(h->cam[which]), P<int32_t>(h->obs_frame),
                      P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->err_partial), np, P<double>(h->err_out));
+    if (with_status)
+        srk_launch_status_pack(s, P<int>(h->info), reinterpret_cast<const int*>(reinterpret_cast<char*>(h->acc.p) + 8 * 3 * d.Ns),
+                               P<double>(h->err_out));
     HIPCHK(h, hipGetLastError());
-    int rc = exchange(h, P<double>(h->err_out), 1);
+    int rc = exchange(h, P<double>(h->err_out), with_status ? 3 : 1);
     if (rc != SRK_OK) return rc;
     if (err_host) {
         HIPCHK(h, hipMemcpyAsync(err_host, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
@@ -772,16 +783,16 @@ static int phase_derivatives(srk_ba* h)
     int c = h->cur;
     HIPCHK(h, hipMemsetAsync(h->Vg.p, 0, 8 * 9 * d.Ns, s));
     HIPCHK(h, hipMemsetAsync(h->Ug.p, 0, 8 * SRK_UG * (int64_t)d.M, s));
-    HIPCHK(h, hipEventRecord(h->ev[12], s));
+    if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[12], s));
     if (h->jac_fused) {
         srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
                              P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg),
                              P<double>(h->Ug), P<int32_t>(h->wg_jmin));
-        HIPCHK(h, hipEventRecord(h->ev[13], s));
+        if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
     } else {
         srk_launch_jac_points(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
                               P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg));
-        HIPCHK(h, hipEventRecord(h->ev[13], s));
+        if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
         srk_launch_jac_frames(s, d, h->max_frame_obs, P<double>(h->pts[c]), P<double>(h->cam[c]),
                               P<int64_t>(h->col_ptr), P<int32_t>(h->fobs_pt), P<double>(h->fobs_uv), P<double>(h->Ug));
     }
@@ -958,9 +969,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     };
     auto ev_ms = [&](int a, int b) {
         float ms = 0;
-        hipEventElapsedTime(&ms, h->ev[a], h->ev[b]);
+        if (h->profile_level < 1 || hipEventElapsedTime(&ms, h->ev[a], h->ev[b]) != hipSuccess) return 0.0;
         return (double)ms;
     };
+#define EVREC(i) do { if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[i], s)); } while (0)
 
     double hessian_factor = (double)0.0001f; // :723 (float literal)
     // seen_points_count over all shards (:483, :726)
@@ -975,10 +987,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     rep->seen = (int64_t)seen_d;
 
     double err_initial = 0;
-    HIPCHK(h, hipEventRecord(h->ev[0], s));
+    EVREC(0);
     int rc = phase_error(h, h->cur, nullptr);
     if (rc != SRK_OK) return fail_device(rc);
-    HIPCHK(h, hipEventRecord(h->ev[1], s));
+    EVREC(1);
     HIPCHK(h, hipMemcpyAsync(&err_initial, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     rep->ms_error += ev_ms(0, 1);
@@ -999,10 +1011,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             break;
         }
         // ComputeCloseFormReprErrorDerivatives (:759)
-        HIPCHK(h, hipEventRecord(h->ev[0], s));
+        EVREC(0);
         rc = phase_derivatives(h);
         if (rc != SRK_OK) return fail_device(rc);
-        HIPCHK(h, hipEventRecord(h->ev[1], s));
+        EVREC(1);
         rep->jacobian_launches += 2;
         bool jac_timed = false;
 
@@ -1012,30 +1024,27 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         int decrease = 0; // 1 success, 2 hessian overflow, 3 converged
         while (!decrease) {
             rep->attempts += 1;
-            HIPCHK(h, hipEventRecord(h->ev[2], s));
+            EVREC(2);
             rc = phase_schur(h, hessian_factor);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipEventRecord(h->ev[3], s));
-            rc = phase_solve(h, h->profile_syrk);
+            EVREC(3);
+            rc = phase_solve(h, h->profile_level >= 2);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipEventRecord(h->ev[4], s));
+            EVREC(4);
             rc = phase_backsub_apply(h, hessian_factor);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipEventRecord(h->ev[5], s));
+            EVREC(5);
             rc = phase_cam_apply(h);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipEventRecord(h->ev[6], s));
-            rc = phase_error(h, 1 - h->cur, nullptr);
+            EVREC(6);
+            rc = phase_error(h, 1 - h->cur, nullptr, true);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipEventRecord(h->ev[7], s));
-            struct { double err; int info; } back;
-            HIPCHK(h, hipMemcpyAsync(&back.err, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipMemcpyAsync(&back.info, h->info.p, 4, hipMemcpyDeviceToHost, s));
-            // the point-update finite flag lives behind acc (set by k_point_update)
-            int info2 = 0;
-            HIPCHK(h, hipMemcpyAsync(&info2, reinterpret_cast<char*>(h->acc.p) + 8 * 3 * d.Ns, 4,
-                                     hipMemcpyDeviceToHost, s));
+            EVREC(7);
+            // one read-back per attempt into pinned host memory: {error, solver info, point-update info}
+            HIPCHK(h, hipMemcpyAsync(h->host_back, h->err_out.p, 24, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
+            struct { double err; int info; } back{ h->host_back[0], (int)h->host_back[1] };
+            const int info2 = (int)h->host_back[2];
             if (!jac_timed) {
                 rep->ms_jacobian += ev_ms(0, 1);
                 rep->ms_jacobian_kernel += ev_ms(12, 13);
@@ -1047,7 +1056,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->ms_apply += ev_ms(5, 6);
             rep->ms_error += ev_ms(6, 7);
             rep->schur_launches += 2;
-            if (h->profile_syrk) {
+            if (h->profile_level >= 2) {
                 for (size_t kb = 0; kb < h->solve_prof.n; ++kb) {
                     float ms = 0;
                     if (hipEventElapsedTime(&ms, h->chol_ev[2 * kb], h->chol_ev[2 * kb + 1]) == hipSuccess)
@@ -1324,10 +1333,10 @@ double srk_ba_solve_mfma_flops(srk_ba* h)
 }
 
 // knob for bench.py: event pairs around every MFMA trailing-update launch (report.ms_solve_syrk)
-int srk_ba_set_profile(srk_ba* h, int profile_syrk)
+int srk_ba_set_profile(srk_ba* h, int level)
 {
-    if (!h) return SRK_E_ARGS;
-    h->profile_syrk = profile_syrk != 0;
+    if (!h || level < 0 || level > 2) return SRK_E_ARGS;
+    h->profile_level = level;
     return SRK_OK;
 }
 

@@ -1031,6 +1031,18 @@ __global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// {solver info, point-update info} next to the error scalar: one 24-byte read-back per LM attempt
+__global__ void k_status_pack(const int* __restrict__ info, const int* __restrict__ info2, double* __restrict__ out)
+{
+    out[1] = (double)info[0];
+    out[2] = (double)info2[0];
+}
+
+void srk_launch_status_pack(hipStream_t s, const int* info, const int* info2, double* out)
+{
+    hipLaunchKernelGGL(k_status_pack, dim3(1), dim3(1), 0, s, info, info2, out);
+}
+
 int32_t srk_error_partials(const SrkDims& d)
 {
     int64_t blocks = (d.O + 255) / 256;

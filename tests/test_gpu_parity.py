@@ -467,7 +467,7 @@ def test_nested_plan_counts_its_mfma_flops(gpu):
             assert r.ms_solve_syrk > 0
             flops[mode] = gpu.solve_mfma_flops()
     finally:
-        gpu.set_profile(False)
+        gpu.set_profile(1)
         gpu.set_rcs_mode(2)
     assert gpu.rcs_chunks() >= 2
     assert flops[0] > flops[1] > 0
