@@ -92,8 +92,11 @@ int srk_ba_set_stream(srk_ba*, void* hip_stream);
 
 /* ---- multi-GPU (landmark sharding) ----
  * Every rank owns a contiguous pnt_ind range and passes only that range to the scene calls; cameras
- * are replicated.  The three exchange steps (frame blocks once per outer iteration; reduced camera
- * system + rhs once per attempt; error scalar) call `fn` to sum `count` doubles in place across ranks.
+ * are replicated.  Two exchange steps per LM attempt call `fn` to sum `count` doubles in place across
+ * ranks: the packed skyline of the assembled reduced camera system with its rhs behind it (the frame
+ * blocks are added before the exchange, so they need none of their own), and {error, solver status,
+ * point-update status}; plus one at the start of an optimise call (initial error, observation count).
+ * Buffers downloaded with srk_ba_download (GRAD, UG, ...) hold this rank's partial sums.
  * `dev_ptr` is device memory on the handle's stream; the hook must return after the reduction is
  * ordered on that stream (or complete).  Returns 0 on success. */
 typedef int (*srk_allreduce_fn)(void* ctx, double* dev_ptr, int64_t count);

@@ -797,7 +797,8 @@ static int phase_derivatives(srk_ba* h)
                               P<int64_t>(h->col_ptr), P<int32_t>(h->fobs_pt), P<double>(h->fobs_uv), P<double>(h->Ug));
     }
     HIPCHK(h, hipGetLastError());
-    return exchange(h, P<double>(h->Ug), SRK_UG * (int64_t)d.M); // frame blocks + frame gradients over all shards
+    // landmark shards: Ug stays this rank's partial sum; it enters the reduced camera system before that is summed
+    return SRK_OK;
 }
 
 static int phase_schur(srk_ba* h, double c)
@@ -812,19 +813,22 @@ static int phase_schur(srk_ba* h, double c)
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());
-    // landmark shards: sum the partial Schur sums and right-hand sides, then add the (global) frame blocks
-    int rc = SRK_OK;
-    if (h->allreduce) { // only the skyline travels: pack -> all-reduce -> unpack
-        if ((rc = dev_alloc(h, h->packed, (size_t)(8 * h->env_packed))) != SRK_OK) return rc;
+    // G (frame blocks, damped) and the frame gradients are linear in this rank's landmarks as well, so they are added
+    // before the exchange; the identity diagonal of fixed / padding variables comes from rank 0 alone
+    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->S), P<double>(h->rhs), h->rank == 0 ? 1.0 : 0.0);
+    HIPCHK(h, hipGetLastError());
+    if (h->allreduce) { // landmark shards: ONE exchange per attempt; only the skyline travels, the rhs rides behind it
+        int rc;
+        if ((rc = dev_alloc(h, h->packed, (size_t)(8 * (h->env_packed + d.ld)))) != SRK_OK) return rc;
+        double* tail = P<double>(h->packed) + h->env_packed;
         srk_launch_env_pack(s, d.ld, P<int64_t>(h->env_col), P<int64_t>(h->env_off), P<double>(h->S), P<double>(h->packed), 0);
-        rc = exchange(h, P<double>(h->packed), h->env_packed);
+        HIPCHK(h, hipMemcpyAsync(tail, h->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
+        rc = exchange(h, P<double>(h->packed), h->env_packed + d.ld);
         if (rc != SRK_OK) return rc;
         srk_launch_env_pack(s, d.ld, P<int64_t>(h->env_col), P<int64_t>(h->env_off), P<double>(h->S), P<double>(h->packed), 1);
+        HIPCHK(h, hipMemcpyAsync(h->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipGetLastError());
     }
-    rc = exchange(h, P<double>(h->rhs), d.ld);
-    if (rc != SRK_OK) return rc;
-    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->S), P<double>(h->rhs));
-    HIPCHK(h, hipGetLastError());
     h->last_hessian_factor = c;
     return SRK_OK;
 }

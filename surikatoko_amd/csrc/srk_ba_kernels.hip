@@ -801,8 +801,10 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
 
 // G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark
 // sums; fixed variables and padding rows get an identity diagonal (:1780-1823, :1902-1908).
+// `ident`: the identity diagonal of fixed / padding variables (1; 0 on all ranks but one when the assembled systems
+// of several landmark shards are summed afterwards).
 __global__ void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, double* __restrict__ S,
-                           double* __restrict__ rhs)
+                           double* __restrict__ rhs, double ident)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t nblk = (int64_t)d.M * 110;
@@ -815,7 +817,7 @@ __global__ void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, d
             int64_t row = 10 * j + v1, col = 10 * j + v2;
             bool fr = srk_is_fixed_var(row, d.comp), fc = srk_is_fixed_var(col, d.comp);
             if (fr || fc) {
-                if (v1 == v2) S[row * d.ld + col] = 1.0;
+                if (v1 == v2) S[row * d.ld + col] = ident;
             } else {
                 int a = v1 < v2 ? v1 : v2, b = v1 < v2 ? v2 : v1;
                 double val = u[a * 10 - a * (a - 1) / 2 + (b - a)];
@@ -831,16 +833,16 @@ __global__ void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, d
     } else {
         int64_t p = 10 * (int64_t)d.M + (t - nblk);
         if (p < d.ld) {
-            S[p * d.ld + p] = 1.0;
+            S[p * d.ld + p] = ident;
             rhs[p] = 0.0;
         }
     }
 }
 
-void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs)
+void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs, double ident)
 {
     int64_t n = (int64_t)d.M * 110 + (d.ld - 10 * (int64_t)d.M);
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, c, Ug, S, rhs);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, c, Ug, S, rhs, ident);
 }
 
 // mirror the lower triangle into the upper one (downloads / exchange of the full matrix)

@@ -57,7 +57,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               const int32_t* obs_frame, const double* W, const double* Vg, double* S, double* rhs,
                               const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups,
                               int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */);
-void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs);
+void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
+                         double ident /* diagonal of fixed / padding variables */);
 void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,
                         const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
                         double* pts_trial, double* dx);

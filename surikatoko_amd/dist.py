@@ -1,9 +1,9 @@
 """Multi-GPU glue: one process per GPU, landmarks sharded, torch.distributed (backend "nccl" = RCCL over xGMI)
-for the three exchange steps of SURVEY 8e.
+for the exchange steps of SURVEY 8e.
 
 The C library calls back (srk_allreduce_fn) with a pointer + element count whenever a buffer has to be summed
-across the landmark shards: the packed frame blocks once per outer iteration, the reduced camera system and its
-right-hand side once per solve attempt, and the error scalar.  The pointer is device memory on the GPU path
+across the landmark shards: twice per LM attempt -- the packed skyline of the assembled reduced camera system with
+its right-hand side behind it, and the error scalar with the solver / point-update status flags.  The pointer is device memory on the GPU path
 (wrapped zero-copy as a torch tensor through __cuda_array_interface__) and host memory in the CPU (gloo) tests.
 """
 import ctypes as C
