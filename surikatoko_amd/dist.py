@@ -38,11 +38,19 @@ def make_allreduce_hook(group=None, device=None, chunk_elems=1 << 27):
 
     def _hook(_ctx, ptr, count):
         try:
+            # a CPU-only backend (gloo) with device pointers: stage through host memory (used to rehearse the
+            # multi-rank path with several processes on one GPU; RCCL reduces in place)
+            stage = device is not None and dist.get_backend(group) == "gloo"
             done = 0
             while done < count:
                 n = min(int(chunk_elems), int(count) - done)
                 t = tensor_from_pointer(int(ptr) + 8 * done, n, device)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                if stage:
+                    th = t.cpu()
+                    dist.all_reduce(th, op=dist.ReduceOp.SUM, group=group)
+                    t.copy_(th)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
                 done += n
             if device is not None:
                 torch.cuda.current_stream(torch.device(device)).synchronize()

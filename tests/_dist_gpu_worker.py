@@ -1,0 +1,45 @@
+"""Worker of tests/test_gpu_multirank.py: one process per rank, all on cuda:0, gloo backend (the hook stages the
+device buffers through host memory).  Runs the product's sharded LM loop end to end and stores this rank's result."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def run(rank, world, port, out_dir, spec_kwargs, iters):
+    import torch.distributed as dist
+    import surikatoko_amd as sa
+    from surikatoko_amd.ba import covisibility, revert_normalization
+    from surikatoko_amd.dist import make_allreduce_hook
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        spec = sa.SceneSpec(**spec_kwargs)
+        full = sa.generate_scene(spec)
+        ok, nrm = sa.normalize_scene_inplace(full)
+        assert ok
+        shard, (lo, hi) = full.shard(rank, world)
+        ba = sa.BundleAdjustmentKanatani(0)
+        hook = make_allreduce_hook(None, "cuda:0")
+        ba.set_allreduce(hook, rank, world)
+        assert ba.upload(spec.f0, shard, already_normalized=True)
+        ba.set_covisibility(covisibility(full))
+        crit = sa.BundleAdjustmentKanataniTermCriteria()
+        crit.AllowedReprojErrRelativeChange(1e-7)
+        ok = ba.optimize(crit, iters)
+        out = shard.copy()
+        ba.download(out, revert_normalization=False)
+        revert_normalization(out, nrm)
+        r = ba.report
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ok=ok, lo=lo, hi=hi, points=out.points, cam_R=out.cam_R,
+                 cam_T=out.cam_T, iterations=r.iterations, attempts=r.attempts, err_initial=r.err_initial,
+                 err_final=r.err_final, seen=r.seen, chunks=ba.rcs_chunks(), status=r.status)
+        ba.close()
+    finally:
+        dist.destroy_process_group()
