@@ -120,6 +120,18 @@ double srk_ba_reproj_error(srk_ba*, double f0,
                            const int64_t* obs_row_ptr, const int32_t* obs_frame, const double* obs_uv,
                            int64_t* seen /* may be NULL */); /* NaN on error */
 
+/* MultiViewIterativeFactorizer::ReprojError (multi-view-factorization.cpp:415-475): the score the MVF driver takes
+ * before deciding to run BA (:372-379).  Observations whose homogeneous image point has |z| <= z_tol (reference:
+ * 1e-5, :455) are skipped.  Returns 1 = ok (*reproj_err and *summands set), 0 = nothing was summed (the reference
+ * returns false), negative = argument / device error.  Both scorers leave an uploaded BA scene untouched and do no
+ * gauge normalisation, sorting or solver planning. */
+int srk_ba_reproj_error_mvf(srk_ba*, double f0,
+                            int64_t n_points, const double* points_xyz,
+                            int32_t n_frames, const double* cam_R, const double* cam_T,
+                            const double* K, int shared_k,
+                            const int64_t* obs_row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                            double z_tol, double* reproj_err, int64_t* summands /* may be NULL */);
+
 /* host-side gauge normalisation (bundle-adj-kanatani.cpp:203-270); no GPU needed */
 int srk_ba_normalize_scene(int64_t n_points, double* points_xyz, int32_t n_frames, double* cam_R, double* cam_T,
                            double t1y, int32_t unity_comp_ind, srk_ba_normalizer* out); /* 1 = ok, 0 = failed */

@@ -133,6 +133,18 @@ public:
         f0_ = f0;
         return e;
     }
+    /// MultiViewIterativeFactorizer::ReprojError (multi-view-factorization.cpp:415-475): the score the MVF driver takes
+    /// before deciding to run BA; shared K only, observations with |z| <= 1e-5 skipped, false when nothing was summed.
+    bool ReprojErrorMvf(Scalar f0, const FragmentMap& map, const std::vector<SE3Transform>& cam_orient_cfw,
+                        const CornerTrackRepository& track_rep, const Matrix3* shared_intrinsic_cam_mat, Scalar* reproj_err) {
+        Flat f = Flatten(f0, map, cam_orient_cfw, track_rep, shared_intrinsic_cam_mat, (const std::vector<Matrix3>*)nullptr);
+        int64_t n = 0;
+        int rc = srk_ba_reproj_error_mvf(h_, f0, (int64_t)f.ids.size(), f.pts.data(), (int32_t)cam_orient_cfw.size(),
+                                         f.R.data(), f.T.data(), f.K.data(), f.shared, f.row_ptr.data(), f.frames.data(),
+                                         f.uv.data(), 1e-5, reproj_err, &n);
+        if (rc < 0) Raise(rc);
+        return rc == 1;
+    }
     Scalar ReprojErrorPixPerPoint(Scalar reproj_err, size_t seen) const { return f0_ * std::sqrt(reproj_err / (Scalar)seen); } // .cpp:602-615
 
     size_t PointsCount() const { return points_count_; }

@@ -474,6 +474,43 @@ double orc_reproj_error(double f0, int64_t N, const double* points, int32_t M, c
     return err_sum;
 }
 
+/* multi-view-factorization.cpp:415-475 MultiViewIterativeFactorizer::ReprojError: the scorer the MVF driver calls
+ * before deciding to run BA (:372-379) -- frames outer, tracks inner, observations whose homogeneous image point
+ * has |z| <= 1e-5 (IsCloseAbs, approx-alg.h:19-23) are skipped; returns 0 (false) when nothing was summed. */
+int orc_reproj_error_mvf(double f0, int64_t N, const double* points, int32_t M, const double* cam_R,
+                         const double* cam_T, const double* K, int32_t shared_k, const int64_t* row_ptr,
+                         const int32_t* obs_frame, const double* obs_uv, double* reproj_err, int64_t* summands)
+{
+    csc_t c;
+    csc_build(N, M, row_ptr, obs_frame, &c);
+    double err_sum = 0;
+    int64_t cnt = 0;
+    for (int32_t j = 0; j < M; ++j) {
+        const double* R = cam_R + 9 * j;
+        const double* T = cam_T + 3 * j;
+        const double* Kj = shared_k ? K : K + 9 * j;
+        for (int64_t k = c.col_ptr[j]; k < c.col_ptr[j + 1]; ++k) {
+            int64_t o = c.obs[k];
+            const double* X = points + 3 * c.pnt[k];
+            double xc[3], xi[3];
+            se3_apply(R, T, X, xc);
+            mat3_vec(Kj, xc, xi);
+            if (fabs(0 - xi[2]) <= 1e-5) continue; /* :455-457 */
+            double x = xi[0] / xi[2];
+            double y = xi[1] / xi[2];
+            double dx = x - obs_uv[2 * o] / f0;
+            double dy = y - obs_uv[2 * o + 1] / f0;
+            err_sum += dx * dx + dy * dy;
+            cnt += 1;
+        }
+    }
+    csc_free(&c);
+    if (summands) *summands = cnt;
+    if (cnt == 0) return 0; /* :470-471 */
+    *reproj_err = err_sum;
+    return 1;
+}
+
 /* ---------------------------------------------------------------- derivatives */
 
 /* BA:1528-1537 FirstDerivFromPqrDerivative (formula 8) */

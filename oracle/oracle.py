@@ -93,6 +93,15 @@ class Scene:
                 C.c_int32(self.shared_k), _i64(self.row_ptr), _i32(self.obs_frame), _d(self.obs_uv))
 
 
+def reproj_error_mvf(f0, sc):
+    """(ok, err, summands) of MultiViewIterativeFactorizer::ReprojError (multi-view-factorization.cpp:415-475)."""
+    e, n = C.c_double(0), C.c_int64(0)
+    f = lib().orc_reproj_error_mvf
+    f.restype = C.c_int
+    ok = f(C.c_double(f0), *sc._args(), C.byref(e), C.byref(n))
+    return bool(ok), e.value, n.value
+
+
 def reproj_error(f0, sc):
     seen = C.c_int64(0)
     e = lib().orc_reproj_error(C.c_double(f0), *sc._args(), C.byref(seen))

@@ -52,7 +52,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 # every symbol include/srk_ba.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "srk_ba_create", "srk_ba_destroy", "srk_ba_last_error", "srk_ba_status_string", "srk_ba_device_count",
-    "srk_ba_set_stream", "srk_ba_set_allreduce", "srk_ba_compute_inplace", "srk_ba_reproj_error",
+    "srk_ba_set_stream", "srk_ba_set_allreduce", "srk_ba_compute_inplace", "srk_ba_reproj_error", "srk_ba_reproj_error_mvf",
     "srk_ba_normalize_scene", "srk_ba_revert_normalization", "srk_ba_check_world_is_normalized",
     "srk_ba_upload_scene", "srk_ba_optimize", "srk_ba_download_scene", "srk_ba_reset_scene", "srk_ba_phase_error",
     "srk_ba_phase_derivatives", "srk_ba_phase_schur", "srk_ba_phase_solve", "srk_ba_phase_backsub",
@@ -90,6 +90,7 @@ def lib():
     L.srk_ba_status_string.restype = C.c_char_p
     L.srk_ba_status_string.argtypes = [C.c_int]
     L.srk_ba_reproj_error.restype = C.c_double
+    L.srk_ba_reproj_error_mvf.restype = C.c_int
     L.srk_ba_buffer_size.restype = C.c_int64
     L.srk_ba_buffer_size.argtypes = [C.c_void_p, C.c_int]
     L.srk_scene_num_observations.restype = C.c_int64

@@ -193,6 +193,20 @@ class BundleAdjustmentKanatani:
         self._f0 = float(f0)
         return float(e), int(seen.value)
 
+    def ReprojErrorMvf(self, f0, scene, z_tol=1e-5):
+        """MultiViewIterativeFactorizer::ReprojError (multi-view-factorization.cpp:415-475) -> (ok, err, summands):
+        the score the MVF driver takes before deciding to run BA; observations with |z| <= z_tol are skipped and
+        ok is False when nothing was summed."""
+        e, n = C.c_double(0), C.c_int64(0)
+        rc = self._lib.srk_ba_reproj_error_mvf(C.c_void_p(self._h), C.c_double(f0), *scene.scene_args(), C.c_double(z_tol),
+                                               C.byref(e), C.byref(n))
+        if rc < 0:
+            msg = self.last_error()
+            if "hip" in msg.lower():
+                raise RuntimeError("srk_ba_reproj_error_mvf: " + msg)
+            raise ValueError("srk_ba_reproj_error_mvf: " + msg)
+        return rc == 1, float(e.value), int(n.value)
+
     def ReprojErrorPixPerPoint(self, reproj_err, seen_points_count):
         """f0 * sqrt(err / seen) (.cpp:602-615)."""
         return self._f0 * math.sqrt(reproj_err / float(seen_points_count))

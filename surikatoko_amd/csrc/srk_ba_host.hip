@@ -50,6 +50,7 @@ struct srk_ba {
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
     DevBuf grp_first, grp_count, gen_list, wg_jmin;
+    DevBuf sc_pts, sc_R, sc_T, sc_K, sc_cam, sc_frame, sc_pt, sc_uv, sc_partial, sc_out; // standalone scoring path
     int64_t n_groups = 0, n_groups_wide = 0, n_generic = 0;
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // skyline of the reduced camera system (see k_env_zero): host + device copies
@@ -162,6 +163,8 @@ void srk_ba_destroy(srk_ba* h)
                       &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv };
     for (DevBuf* b : all) dev_free(*b);
     for (DevBuf& b : h->plan_bufs) dev_free(b);
+    for (DevBuf* b : { &h->sc_pts, &h->sc_R, &h->sc_T, &h->sc_K, &h->sc_cam, &h->sc_frame, &h->sc_pt, &h->sc_uv, &h->sc_partial, &h->sc_out })
+        dev_free(*b);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : h->chol_ev) hipEventDestroy(e);
@@ -283,12 +286,12 @@ void srk_ba_revert_normalization(int64_t N, double* pts, int32_t M, double* cam_
 
 static int validate_scene(srk_ba* h, double f0, int64_t N, const double* pts, int32_t M, const double* cam_R,
                           const double* cam_T, const double* K, const int64_t* row_ptr, const int32_t* obs_frame,
-                          const double* obs_uv)
+                          const double* obs_uv, int32_t min_frames = 2)
 {
     if (!h) return SRK_E_ARGS;
     // CHECK(!IsClose(0, f0)) (:420)
     if (srk::is_close(0.0, f0)) { h->last_error = "f0 must not be ~0"; return SRK_E_ARGS; }
-    if (M < 2) { h->last_error = "need at least two frames"; return SRK_E_ARGS; }
+    if (M < min_frames) { h->last_error = min_frames > 1 ? "need at least two frames" : "need at least one frame"; return SRK_E_ARGS; }
     if (N < 0 || !cam_R || !cam_T || !K || !row_ptr) { h->last_error = "null scene array"; return SRK_E_ARGS; }
     if (N > 0 && !pts) { h->last_error = "null points"; return SRK_E_ARGS; }
     if (N > 2147483000LL) { h->last_error = "too many points for int32 indices"; return SRK_E_ARGS; }
@@ -1126,16 +1129,78 @@ int srk_ba_compute_inplace(srk_ba* h, double f0, int64_t N, double* pts, int32_t
     return result;
 }
 
+// Standalone scoring: ReprojError callers that only score a scene (multi-view-factorization.cpp:373,409-413) do not
+// need the LM state -- no gauge normalisation, landmark sort, grouping or solver plan; the uploaded BA scene (if any)
+// stays untouched.  z_tol < 0 keeps every observation (BundleAdjustmentKanatani::ReprojError, :589-600).
+static int score_scene(srk_ba* h, double f0, int64_t N, const double* pts, int32_t M, const double* cam_R,
+                       const double* cam_T, const double* K, int shared_k, const int64_t* row_ptr,
+                       const int32_t* obs_frame, const double* obs_uv, int32_t min_frames, double z_tol, double* err,
+                       int64_t* count)
+{
+    int rc = validate_scene(h, f0, N, pts, M, cam_R, cam_T, K, row_ptr, obs_frame, obs_uv, min_frames);
+    if (rc != SRK_OK) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int64_t O = row_ptr[N];
+    std::vector<int32_t> obs_pt((size_t)O);
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o) obs_pt[(size_t)o] = (int32_t)i;
+    std::vector<double> Kexp(9 * (size_t)M);
+    for (int32_t j = 0; j < M; ++j) std::memcpy(&Kexp[9 * (size_t)j], shared_k ? K : K + 9 * (int64_t)j, 72);
+    SrkDims d{};
+    d.O = O;
+    const int32_t np = srk_error_partials(d);
+    struct { DevBuf* b; const void* src; size_t bytes; } up[] = {
+        { &h->sc_pts, pts, (size_t)(24 * N) },          { &h->sc_R, cam_R, (size_t)(72 * (int64_t)M) },
+        { &h->sc_T, cam_T, (size_t)(24 * (int64_t)M) }, { &h->sc_K, Kexp.data(), (size_t)(72 * (int64_t)M) },
+        { &h->sc_frame, obs_frame, (size_t)(4 * O) },   { &h->sc_pt, obs_pt.data(), (size_t)(4 * O) },
+        { &h->sc_uv, obs_uv, (size_t)(16 * O) },
+    };
+    for (auto& u : up) {
+        if ((rc = dev_alloc(h, *u.b, u.bytes)) != SRK_OK) return rc;
+        if (u.bytes) HIPCHK(h, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = dev_alloc(h, h->sc_cam, (size_t)(8 * SRK_CAM_PACK * (int64_t)M))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, h->sc_partial, (size_t)(16 * np))) != SRK_OK) return rc;
+    if ((rc = dev_alloc(h, h->sc_out, 16)) != SRK_OK) return rc;
+    srk_launch_cam_pack(s, M, P<double>(h->sc_R), P<double>(h->sc_T), P<double>(h->sc_K), f0, P<double>(h->sc_cam));
+    srk_launch_error_score(s, O, P<double>(h->sc_pts), P<double>(h->sc_cam), P<int32_t>(h->sc_frame), P<int32_t>(h->sc_pt),
+                           P<double>(h->sc_uv), z_tol, P<double>(h->sc_partial), np, P<double>(h->sc_out));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->host_back, h->sc_out.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    *err = h->host_back[0];
+    *count = (int64_t)h->host_back[1];
+    return SRK_OK;
+}
+
 double srk_ba_reproj_error(srk_ba* h, double f0, int64_t N, const double* pts, int32_t M, const double* cam_R,
                            const double* cam_T, const double* K, int shared_k, const int64_t* row_ptr,
                            const int32_t* obs_frame, const double* obs_uv, int64_t* seen)
 {
     if (!h) return std::nan("");
-    int rc = srk_ba_upload_scene(h, f0, N, pts, M, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv, 1);
-    if (rc != SRK_OK) return std::nan("");
     double e = std::nan("");
-    if (srk_ba_phase_error(h, &e, seen) != SRK_OK) return std::nan("");
+    int64_t cnt = 0;
+    if (score_scene(h, f0, N, pts, M, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv, 2, -1.0, &e, &cnt) != SRK_OK)
+        return std::nan("");
+    if (seen) *seen = cnt;
     return e;
+}
+
+int srk_ba_reproj_error_mvf(srk_ba* h, double f0, int64_t N, const double* pts, int32_t M, const double* cam_R,
+                            const double* cam_T, const double* K, int shared_k, const int64_t* row_ptr,
+                            const int32_t* obs_frame, const double* obs_uv, double z_tol, double* reproj_err,
+                            int64_t* summands)
+{
+    if (!h || !reproj_err || z_tol < 0) return SRK_E_ARGS;
+    double e = 0;
+    int64_t cnt = 0;
+    int rc = score_scene(h, f0, N, pts, M, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv, 1, z_tol, &e, &cnt);
+    if (rc != SRK_OK) return rc;
+    if (summands) *summands = cnt;
+    if (cnt == 0) return 0; // no points, or every point at infinity: the reference returns false (:470-471)
+    *reproj_err = e;
+    return 1;
 }
 
 // ------------------------------------------------------------------ downloads for the parity tests

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     constexpr int W_LM = SRK_GRP_MAXNF * SRK_GRP_WS, Y_LM = SRK_GRP_MAXNF * 30; // doubles per staged landmark
     constexpr int CAP = SRK_GRP_PB * (W_LM + Y_LM);
     __shared__ __attribute__((aligned(16))) double sBuf[CAP];
-    __shared__ double sE[SRK_GRP_MAXPTS][12];
+    __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
     __shared__ int32_t sF[SRK_GRP_MAXNF];
     double* const sW = sBuf;
     double* const sY = sBuf + SRK_GRP_PB * W_LM;
@@ -660,11 +660,12 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int cc = 0; cc < 10; ++cc) acc[s][i][cc] = 0;
-    double racc = 0; // rhs accumulator: thread t < 10 nf owns entry (a = t / 10, r = t % 10)
     // staging map (the same for every round): element idx = tid + j THREADS -> W row k = idx / (PB nf), position q in
-    // the round's PB nf consecutive observations (coalesced over q); LDS slot of (landmark q / nf, frame q % nf, k)
+    // the round's PB nf consecutive observations (coalesced over q); LDS slot of (landmark q / nf, frame q % nf, k).
+    // Everything per-thread is worked out here, once: the round loop below only adds the round's offset.
     const int qn = SRK_GRP_PB * nf;
-    int goff[SRK_GRP_PRE], loff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
+    const double* gp[SRK_GRP_PRE];
+    int loff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
 #pragma unroll
     for (int j = 0; j < SRK_GRP_PRE; ++j) {
         int idx = tid + j * SRK_GRP_THREADS;
@@ -673,18 +674,31 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         int pl = q / nf, a = q - pl * nf;
         int m = k / 10, r = k - 10 * m;
         qpos[j] = in ? q : (1 << 30);
-        goff[j] = in ? q : 0;
         loff[j] = in ? pl * W_LM + a * SRK_GRP_WS + 12 * m + r + (r >= 5) : 0;
-        // W row k, folded into the 64-bit base below to keep the per-round address a single add
-        goff[j] |= (in ? k : 0) << 16; // q < PB * MAXNF < 65536
+        gp[j] = W + (in ? (int64_t)k * d.Os + o0 + q : 0);
+    }
+    // Y stage map: item t = tid + i THREADS -> (staging slot pl, frame a, frame variable fv).  The same thread also
+    // accumulates rhs: W^T (E^-1 g) of ITS staging slot; the PB slots of one (a, fv) are summed by the flush atomics.
+    constexpr int YI = (SRK_GRP_PB * SRK_GRP_MAXNF * 10 + SRK_GRP_THREADS - 1) / SRK_GRP_THREADS;
+    int ypl[YI], ywo[YI], yyo[YI], yrow[YI];
+    double racc[YI];
+#pragma unroll
+    for (int i = 0; i < YI; ++i) {
+        int t = tid + i * SRK_GRP_THREADS;
+        int pl = t / (nf * 10), e = t - pl * nf * 10;
+        int a = e / 10, fv = e - a * 10;
+        ypl[i] = pl < SRK_GRP_PB ? pl : (1 << 30);
+        ywo[i] = pl * W_LM + a * SRK_GRP_WS + fv + (fv >= 5);
+        yyo[i] = pl * Y_LM + a * 30 + fv;
+        yrow[i] = e;
+        racc[i] = 0;
     }
     double pre[SRK_GRP_PRE];
     auto prefetch = [&](int pb) {
         const int nq = (np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB) * nf;
-        const double* base = W + o0 + (int64_t)pb * nf;
+        const int64_t adv = (int64_t)pb * nf;
 #pragma unroll
-        for (int j = 0; j < SRK_GRP_PRE; ++j)
-            pre[j] = qpos[j] < nq ? base[(int64_t)(goff[j] >> 16) * d.Os + (goff[j] & 0xffff)] : 0.0;
+        for (int j = 0; j < SRK_GRP_PRE; ++j) pre[j] = qpos[j] < nq ? gp[j][adv] : 0.0;
     };
     prefetch(0);
     for (int pb = 0; pb < np; pb += SRK_GRP_PB) {
@@ -694,16 +708,18 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         for (int j = 0; j < SRK_GRP_PRE; ++j)
             if (qpos[j] < nb * nf) sW[loff[j]] = pre[j];
         __syncthreads();
-        for (int t = tid; t < nb * nf * 10; t += SRK_GRP_THREADS) {
-            int pl = t / (nf * 10), e = t - pl * nf * 10;
-            int a = e / 10, fv = e - a * 10;
-            const double* Ei = sE[pb + pl];
-            const double* wp = sW + pl * W_LM + a * SRK_GRP_WS + fv + (fv >= 5);
-            double w0 = wp[0], w1 = wp[12], w2 = wp[24];
-            double* yp = sY + pl * Y_LM + a * 30 + fv;
-            yp[0] = Ei[0] * w0 + Ei[1] * w1 + Ei[2] * w2;
-            yp[10] = Ei[3] * w0 + Ei[4] * w1 + Ei[5] * w2;
-            yp[20] = Ei[6] * w0 + Ei[7] * w1 + Ei[8] * w2;
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            if (ypl[i] >= nb) continue;
+            const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl[i]]); // rows are 96 B: 16-byte aligned
+            const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
+            const double* wp = sW + ywo[i];
+            const double w0 = wp[0], w1 = wp[12], w2 = wp[24];
+            double* yp = sY + yyo[i];
+            yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
+            yp[10] = e23.y * w0 + e45.x * w1 + e45.y * w2;
+            yp[20] = e67.x * w0 + e67.y * w1 + e89.x * w2;
+            racc[i] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
         }
         if (pb + SRK_GRP_PB < np) prefetch(pb + SRK_GRP_PB); // in flight while this round is multiplied
         __syncthreads();
@@ -733,12 +749,6 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
                         }
                     }
                 }
-            }
-            if (tid < nf * 10) {
-                int a = tid / 10, r = tid - a * 10;
-                const double* Eg = sE[pb + pl] + 9;
-                const double* wp = w + a * SRK_GRP_WS + r + (r >= 5);
-                racc += wp[0] * Eg[0] + wp[12] * Eg[1] + wp[24] * Eg[2];
             }
         }
     }
@@ -779,10 +789,12 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         }
         a0 = a1;
     }
-    if (tid < nf * 10) {
-        int a = tid / 10, r = tid - a * 10;
+#pragma unroll
+    for (int i = 0; i < YI; ++i) {
+        if (ypl[i] >= SRK_GRP_PB || ypl[i] >= np) continue; // a slot that never held a landmark
+        int a = yrow[i] / 10, r = yrow[i] - a * 10;
         int64_t row = 10 * (int64_t)sF[a] + r;
-        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], racc);
+        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], racc[i]);
     }
 }
 
@@ -1017,6 +1029,44 @@ __global__ __launch_bounds__(256) void k_error(SrkDims d, const double* __restri
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// scoring variant (MultiViewIterativeFactorizer::ReprojError, multi-view-factorization.cpp:415-475): observations whose
+// homogeneous image point has |z| <= z_tol are skipped (:455-457) and the summands are counted; z_tol < 0 keeps all.
+// partial[0 .. grid) = error sums, partial[grid .. 2 grid) = counts.
+__global__ __launch_bounds__(256) void k_error_score(int64_t O, const double* __restrict__ pts,
+                                                     const double* __restrict__ cam, const int32_t* __restrict__ obs_frame,
+                                                     const int32_t* __restrict__ obs_pt, const double* __restrict__ obs_uv,
+                                                     double z_tol, double* __restrict__ partial)
+{
+    __shared__ double red[8];
+    double sum = 0, cnt = 0;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < O; o += (int64_t)gridDim.x * 256) {
+        const double* c = cam + (int64_t)SRK_CAM_PACK * obs_frame[o];
+        double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
+        const double* X = pts + 3 * (int64_t)obs_pt[o];
+        double X0 = X[0], X1 = X[1], X2 = X[2];
+        double xc0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+        double xc1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+        double xc2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+        double p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
+        double q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
+        double r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
+        if (fabs(r) <= z_tol) continue;
+        double f0 = c[47];
+        double ex = p / r - uv.x / f0, ey = q / r - uv.y / f0;
+        sum += ex * ex + ey * ey;
+        cnt += 1.0;
+    }
+    sum = wave_sum(sum);
+    cnt = wave_sum(cnt);
+    int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = sum, red[4 + wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        partial[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
 // fixed-order final sum: the LM accept/reject decision must not depend on atomic arrival order
 __global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __restrict__ partial,
                                                      double* __restrict__ out)
@@ -1059,6 +1109,16 @@ void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const 
     hipLaunchKernelGGL(k_error, dim3((unsigned)n_partial), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
                        partial);
     hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, err_out);
+}
+
+void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const double* cam, const int32_t* obs_frame,
+                            const int32_t* obs_pt, const double* obs_uv, double z_tol, double* partial /* 2 n */,
+                            int32_t n_partial, double* out2)
+{
+    hipLaunchKernelGGL(k_error_score, dim3((unsigned)n_partial), dim3(256), 0, s, O, pts, cam, obs_frame, obs_pt, obs_uv,
+                       z_tol, partial);
+    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, out2);
+    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial + n_partial, out2 + 1);
 }
 
 // ------------------------------------------------------------------ skyline (envelope) helpers for the RCS

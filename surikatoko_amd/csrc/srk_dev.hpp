@@ -68,6 +68,9 @@ void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const 
                       const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
                       int32_t n_partial, double* err_out);
 int32_t srk_error_partials(const SrkDims& d);
+void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const double* cam, const int32_t* obs_frame,
+                            const int32_t* obs_pt, const double* obs_uv, double z_tol /* < 0: keep every observation */,
+                            double* partial /* 2 n_partial */, int32_t n_partial, double* out2 /* {error, count} */);
 void srk_launch_status_pack(hipStream_t s, const int* info, const int* info2, double* out /* [3]: out[1..2] written */);
 void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full);
 void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);

@@ -47,6 +47,11 @@ int main()
     BundleAdjustmentKanatani ba;
     size_t seen = 0;
     double e0 = ba.ReprojError(1.0, map, cams, rep, &sharedK, nullptr, &seen);
+    // the MVF driver's own scorer (multi-view-factorization.cpp:372-379): no point is at infinity here, so it must
+    // agree with the BA scorer; ~1e-3 is the threshold above which the driver runs BA
+    double e_mvf = -1;
+    if (!ba.ReprojErrorMvf(1.0, map, cams, rep, &sharedK, &e_mvf)) return 13;
+    if (std::fabs(e_mvf - e0) > 1e-12 * std::fabs(e0)) return 14;
     bool ok = ba.ComputeInplace(1.0, map, cams, rep, &sharedK, nullptr, crit);
 
     // reference run through the C ABI on the flat arrays

@@ -475,3 +475,49 @@ def test_nested_plan_counts_its_mfma_flops(gpu):
         gpu.set_rcs_mode(2)
     assert gpu.rcs_chunks() >= 2
     assert flops[0] > flops[1] > 0
+
+
+# ------------------------------------------------------------------ standalone scoring
+
+def test_reproj_error_does_not_disturb_an_uploaded_scene(orc, gpu):
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    assert gpu.upload(spec.f0, sc)
+    e_before, _ = gpu.phase_error()
+    other = sa.generate_scene(SCENES["tiny"])
+    e, seen = gpu.ReprojError(spec.f0, other)
+    eo, so = orc.reproj_error(spec.f0, _orc_scene(orc, other))
+    assert seen == so and e == pytest.approx(eo, rel=1e-12)
+    assert gpu.phase_error()[0] == e_before  # the resident BA scene is untouched
+
+
+def test_mvf_scorer_matches_oracle_and_skips_points_at_infinity(orc, gpu):
+    """MultiViewIterativeFactorizer::ReprojError (multi-view-factorization.cpp:415-475): shared K, f0 = 1, |z| <= 1e-5
+    skipped, false when nothing is summed."""
+    spec = sa.SceneSpec(n_frames=9, grid_nx=7, grid_ny=6, vis_window=4, f0=1.0)
+    sc = sa.generate_scene(spec)
+    ok, e, n = gpu.ReprojErrorMvf(1.0, sc)
+    oko, eo, no = orc.reproj_error_mvf(1.0, _orc_scene(orc, sc))
+    assert ok and oko and n == no == sc.O
+    assert e == pytest.approx(eo, rel=1e-12)
+    # move three landmarks into the focal plane of one of the cameras that sees them: z_cam = 0 -> skipped there only
+    s2 = sc.copy()
+    moved = 0
+    for i in (0, 5, 11):
+        j = int(s2.obs_frame[s2.row_ptr[i]])
+        R, T = s2.cam_R[j].reshape(3, 3), s2.cam_T[j]
+        xc = R @ s2.points[i] + T
+        xc[2] = 0.0
+        s2.points[i] = R.T @ (xc - T)
+        moved += 1
+    ok2, e2, n2 = gpu.ReprojErrorMvf(1.0, s2)
+    oko2, eo2, no2 = orc.reproj_error_mvf(1.0, _orc_scene(orc, s2))
+    assert ok2 and oko2 and n2 == no2 and sc.O - n2 >= moved
+    assert e2 == pytest.approx(eo2, rel=1e-12)
+    # a single frame is a legal MVF call; nothing to sum -> False
+    one = sa.Scene(sc.points[:2], sc.cam_R[:1], sc.cam_T[:1], sc.K[:1], 1, np.array([0, 0, 0], dtype=np.int64),
+                   np.zeros(0, dtype=np.int32), np.zeros((0, 2)))
+    ok3, _, n3 = gpu.ReprojErrorMvf(1.0, one)
+    assert not ok3 and n3 == 0
+    with pytest.raises(ValueError):
+        gpu.ReprojErrorMvf(0.0, sc)
