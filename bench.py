@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3_1kcam_100kpt")
+    ap.add_argument("--drop", type=float, default=0.0,
+                    help="remove this fraction of the observations at random (ragged tracks; not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
     ap.add_argument("--no-dense-probe", action="store_true")
@@ -98,6 +100,8 @@ def main():
 
     spec = sa.CONFIGS[args.config]
     scene = sa.generate_scene(spec)
+    if args.drop > 0:
+        scene = sa.drop_observations(scene, args.drop, seed=1)
     N_total, M, O_total = scene.N, scene.M, scene.O
     # gauge-normalise ONCE on the whole scene so that every shard sees the same normalised cameras
     ok, _nrm = sa.normalize_scene_inplace(scene)
@@ -264,7 +268,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {M} cams / {N_total} pts / {O_total} obs (circle-grid, "
+            "config": {"workload": (f"ragged tracks ({args.drop:.0%} of the observations dropped) of " if args.drop > 0 else "") +
+                                   f"{args.config}: {M} cams / {N_total} pts / {O_total} obs (circle-grid, "
                                    f"{spec.vis_window}-frame visibility window, f0={spec.f0:g}); one outer LM "
                                    "iteration per step from the same uploaded state",
                        "parallelism": f"landmark shards x{world}" if world > 1 else "single GPU",

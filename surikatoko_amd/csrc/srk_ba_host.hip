@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <iterator>
 #include <memory>
 #include <vector>
 
@@ -49,7 +50,7 @@ struct srk_ba {
     DevBuf W, Vg, Ug, S, rhs, wy, dc, acc, dx, err_partial, err_out, info, scratch;
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
-    DevBuf grp_first, grp_count, gen_list, wg_jmin;
+    DevBuf grp_first, grp_count, grp_nf, grp_frames, obs_slot, pt_mask, gen_list, wg_jmin;
     DevBuf sc_pts, sc_R, sc_T, sc_K, sc_cam, sc_frame, sc_pt, sc_uv, sc_partial, sc_out; // standalone scoring path
     int64_t n_groups = 0, n_groups_wide = 0, n_generic = 0;
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
@@ -159,7 +160,7 @@ void srk_ba_destroy(srk_ba* h)
     DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->camR[0], &h->camR[1], &h->camT[0], &h->camT[1], &h->K, &h->cam[0],
                       &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
                       &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
-                      &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count,
+                      &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
                       &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv };
     for (DevBuf* b : all) dev_free(*b);
     for (DevBuf& b : h->plan_bufs) dev_free(b);
@@ -530,7 +531,6 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         return false;
     };
     std::stable_sort(order.begin(), order.end(), list_less);
-    auto same_list = [&](int64_t x, int64_t y) { return !list_less(x, y) && !list_less(y, x); };
     h->perm = order;
     h->row_ptr_user.assign(row_ptr, row_ptr + N + 1);
     std::vector<int64_t> rp((size_t)N + 1, 0);
@@ -549,24 +549,55 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     row_ptr = rp.data();
     obs_frame = of.data();
     obs_uv = ouv.data();
-    // runs of identical frame lists -> grouped kernel (<= SRK_GRP_MAXNF_HOST frames); the rest -> generic kernel
-    std::vector<int32_t> grp_first, grp_count, gen_list;
+    // Runs of consecutive landmarks (internal order) whose frame lists fit a common set of <= SRK_GRP_MAXNF_HOST
+    // frames -> grouped Schur kernel: the run's blocks are accumulated over that UNION of frames, a landmark that does
+    // not see one of them contributes zeros there.  Identical lists (the circle-grid scenes) are the special case
+    // union == list ("uniform" run: no slot table needed); ragged feature tracks, where hardly two landmarks see
+    // exactly the same frames, still share a window of frames.  Landmarks with more frames -> per-landmark kernel.
+    std::vector<int32_t> grp_first, grp_count, grp_nf, grp_frames, gen_list;
+    std::vector<uint8_t> obs_slot((size_t)O, 0);
+    std::vector<uint32_t> pt_mask((size_t)N, 0);
     int64_t n_wide = 0;
-    for (int64_t i = 0; i < N;) {
-        int64_t j = i + 1;
-        while (j < N && same_list(i, j)) ++j; // internal indices: row_ptr / obs_frame now are the permuted arrays
-        int64_t nf = rp[(size_t)i + 1] - rp[(size_t)i];
-        if (nf >= 1 && nf <= SRK_GRP_MAXNF_HOST) {
-            for (int64_t k = i; k < j; k += SRK_GRP_MAXPTS_HOST) {
-                grp_first.push_back((int32_t)k);
-                grp_count.push_back((int32_t)std::min<int64_t>(SRK_GRP_MAXPTS_HOST, j - k));
-                if (nf > SRK_GRP_NF1_HOST) ++n_wide;
+    {
+        std::vector<int32_t> uni, merged;
+        for (int64_t i = 0; i < N;) {
+            const int64_t nfi = rp[(size_t)i + 1] - rp[(size_t)i];
+            if (nfi == 0) { ++i; continue; }
+            if (nfi > SRK_GRP_MAXNF_HOST) { gen_list.push_back((int32_t)i); ++i; continue; }
+            const int64_t cap = nfi > SRK_GRP_NF1_HOST ? SRK_GRP_MAXNF_HOST : SRK_GRP_NF1_HOST;
+            uni.assign(of.begin() + rp[(size_t)i], of.begin() + rp[(size_t)i + 1]);
+            int64_t j = i + 1;
+            while (j < N && j - i < SRK_GRP_MAXPTS_HOST) {
+                const int64_t nfj = rp[(size_t)j + 1] - rp[(size_t)j];
+                if (nfj == 0 || nfj > cap) break;
+                merged.clear();
+                std::set_union(uni.begin(), uni.end(), of.begin() + rp[(size_t)j], of.begin() + rp[(size_t)j + 1],
+                               std::back_inserter(merged));
+                if ((int64_t)merged.size() > cap) break;
+                // a wider frame set costs every landmark of the run more flops; it only pays while the run is still
+                // small against its one-off flush (~ the work of a dozen landmarks)
+                if (merged.size() > uni.size() && j - i >= 24) break;
+                uni.swap(merged);
+                ++j;
             }
-        } else {
-            for (int64_t k = i; k < j; ++k)
-                if (nf > 0) gen_list.push_back((int32_t)k);
+            bool uniform = true;
+            for (int64_t p = i; p < j; ++p) {
+                uint32_t mask = 0;
+                for (int64_t o = rp[(size_t)p]; o < rp[(size_t)p + 1]; ++o) {
+                    int slot = (int)(std::lower_bound(uni.begin(), uni.end(), of[(size_t)o]) - uni.begin());
+                    obs_slot[(size_t)o] = (uint8_t)slot;
+                    mask |= 1u << slot;
+                }
+                pt_mask[(size_t)p] = mask;
+                uniform = uniform && (rp[(size_t)p + 1] - rp[(size_t)p] == (int64_t)uni.size());
+            }
+            grp_first.push_back((int32_t)i);
+            grp_count.push_back((int32_t)(j - i));
+            grp_nf.push_back(uniform ? (int32_t)uni.size() : -(int32_t)uni.size()); // negative = ragged run
+            for (int k = 0; k < SRK_GRP_MAXNF_HOST; ++k) grp_frames.push_back(k < (int)uni.size() ? uni[(size_t)k] : -1);
+            if ((int64_t)uni.size() > SRK_GRP_NF1_HOST) ++n_wide;
+            i = j;
         }
-        i = j;
     }
     h->n_groups = (int64_t)grp_first.size();
     h->n_groups_wide = n_wide;
@@ -661,6 +692,10 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->info, 64);
     ALLOC(h->grp_first, 4 * grp_first.size());
     ALLOC(h->grp_count, 4 * grp_count.size());
+    ALLOC(h->grp_nf, 4 * grp_nf.size());
+    ALLOC(h->grp_frames, 4 * grp_frames.size());
+    ALLOC(h->obs_slot, obs_slot.size());
+    ALLOC(h->pt_mask, 4 * pt_mask.size());
     ALLOC(h->gen_list, 4 * gen_list.size());
     ALLOC(h->wg_jmin, 4 * wg_jmin.size());
     ALLOC(h->dinv, 8 * 64 * d.ld);
@@ -686,6 +721,10 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->fobs_uv, fobs_uv.data(), 16 * O);
     H2D(h->grp_first, grp_first.data(), 4 * grp_first.size());
     H2D(h->grp_count, grp_count.data(), 4 * grp_count.size());
+    H2D(h->grp_nf, grp_nf.data(), 4 * grp_nf.size());
+    H2D(h->grp_frames, grp_frames.data(), 4 * grp_frames.size());
+    H2D(h->obs_slot, obs_slot.data(), obs_slot.size());
+    H2D(h->pt_mask, pt_mask.data(), 4 * pt_mask.size());
     H2D(h->gen_list, gen_list.data(), 4 * gen_list.size());
     H2D(h->wg_jmin, wg_jmin.data(), 4 * wg_jmin.size());
 #undef H2D
@@ -810,9 +849,10 @@ static int phase_schur(srk_ba* h, double c)
     hipStream_t s = h->stream;
     srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->S));
     HIPCHK(h, hipMemsetAsync(h->rhs.p, 0, 8 * d.ld, s));
-    srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W),
-                             P<double>(h->Vg), P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->grp_first),
-                             P<int32_t>(h->grp_count), h->n_groups, h->n_groups_wide);
+    srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
+                             P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->S),
+                             P<double>(h->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
+                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());

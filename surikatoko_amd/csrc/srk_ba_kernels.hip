@@ -607,9 +607,11 @@ static_assert(SRK_GRP_NF1 * (SRK_GRP_NF1 + 1) <= SRK_GRP_THREADS && SRK_GRP_MAXN
 
 template <int SLOTS>
 __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
-    SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_frame,
-    const double* __restrict__ W, const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
-    const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count)
+    SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
+    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
+    const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
+    const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
+    const int32_t* __restrict__ grp_frames)
 {
     // one LDS arena: W | Y staging during the accumulation, then the staging buffer of the coalesced flush
     constexpr int W_LM = SRK_GRP_MAXNF * SRK_GRP_WS, Y_LM = SRK_GRP_MAXNF * 30; // doubles per staged landmark
@@ -617,15 +619,18 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     __shared__ __attribute__((aligned(16))) double sBuf[CAP];
     __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
     __shared__ int32_t sF[SRK_GRP_MAXNF];
+    __shared__ uint32_t sM[SRK_GRP_PB]; // ragged runs: the frame slots each staged landmark sees
     double* const sW = sBuf;
     double* const sY = sBuf + SRK_GRP_PB * W_LM;
     const int tid = threadIdx.x;
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
-    const int64_t o0 = row_ptr[p0];
-    const int nf = (int)(row_ptr[p0 + 1] - o0);
+    // the run's frame set (union of its landmarks' frame lists); ragged = some landmark misses some of these frames
+    const int nfu = grp_nf[blockIdx.x];
+    const bool ragged = nfu < 0;
+    const int nf = ragged ? -nfu : nfu;
     if ((SLOTS == 1) != (nf <= SRK_GRP_NF1)) return; // the other instantiation takes this run
-    if (tid < nf) sF[tid] = obs_frame[o0 + tid];
+    if (tid < nf) sF[tid] = grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid];
     if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
         double Einv[9], g[3];
         bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     // Everything per-thread is worked out here, once: the round loop below only adds the round's offset.
     const int qn = SRK_GRP_PB * nf;
     const double* gp[SRK_GRP_PRE];
-    int loff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
+    int loff[SRK_GRP_PRE], koff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
 #pragma unroll
     for (int j = 0; j < SRK_GRP_PRE; ++j) {
         int idx = tid + j * SRK_GRP_THREADS;
@@ -674,13 +679,14 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         int pl = q / nf, a = q - pl * nf;
         int m = k / 10, r = k - 10 * m;
         qpos[j] = in ? q : (1 << 30);
-        loff[j] = in ? pl * W_LM + a * SRK_GRP_WS + 12 * m + r + (r >= 5) : 0;
-        gp[j] = W + (in ? (int64_t)k * d.Os + o0 + q : 0);
+        koff[j] = 12 * m + r + (r >= 5);
+        loff[j] = in ? pl * W_LM + a * SRK_GRP_WS + koff[j] : 0; // uniform runs: landmark q / nf, slot q % nf
+        gp[j] = W + (in ? (int64_t)k * d.Os + q : 0);
     }
     // Y stage map: item t = tid + i THREADS -> (staging slot pl, frame a, frame variable fv).  The same thread also
     // accumulates rhs: W^T (E^-1 g) of ITS staging slot; the PB slots of one (a, fv) are summed by the flush atomics.
     constexpr int YI = (SRK_GRP_PB * SRK_GRP_MAXNF * 10 + SRK_GRP_THREADS - 1) / SRK_GRP_THREADS;
-    int ypl[YI], ywo[YI], yyo[YI], yrow[YI];
+    int ypl[YI], ywo[YI], yyo[YI], yrow[YI], ya[YI];
     double racc[YI];
 #pragma unroll
     for (int i = 0; i < YI; ++i) {
@@ -691,37 +697,64 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         ywo[i] = pl * W_LM + a * SRK_GRP_WS + fv + (fv >= 5);
         yyo[i] = pl * Y_LM + a * 30 + fv;
         yrow[i] = e;
+        ya[i] = a;
         racc[i] = 0;
     }
+    // The observations of the round's landmarks are contiguous: [row_ptr[p0 + pb], row_ptr[p0 + pb + nb]).  Ragged runs
+    // also fetch each observation's (staged landmark, frame slot) and the landmarks' slot masks.
     double pre[SRK_GRP_PRE];
+    int pdst[SRK_GRP_PRE];
+    uint32_t pmask = 0;
     auto prefetch = [&](int pb) {
-        const int nq = (np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB) * nf;
-        const int64_t adv = (int64_t)pb * nf;
+        const int nbn = np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB;
+        const int64_t oa = row_ptr[p0 + pb];
+        const int nq = (int)(row_ptr[p0 + pb + nbn] - oa);
 #pragma unroll
-        for (int j = 0; j < SRK_GRP_PRE; ++j) pre[j] = qpos[j] < nq ? gp[j][adv] : 0.0;
+        for (int j = 0; j < SRK_GRP_PRE; ++j) pre[j] = qpos[j] < nq ? gp[j][oa] : 0.0;
+        if (ragged) {
+#pragma unroll
+            for (int j = 0; j < SRK_GRP_PRE; ++j)
+                if (qpos[j] < nq)
+                    pdst[j] = (obs_pt[oa + qpos[j]] - (int)(p0 + pb)) * W_LM + (int)obs_slot[oa + qpos[j]] * SRK_GRP_WS + koff[j];
+            if (tid < nbn) pmask = pt_mask[p0 + pb + tid];
+        }
+        return nq;
     };
-    prefetch(0);
+    int nq_next = prefetch(0);
     for (int pb = 0; pb < np; pb += SRK_GRP_PB) {
         const int nb = np - pb < SRK_GRP_PB ? np - pb : SRK_GRP_PB;
+        const int nq = nq_next;
         __syncthreads(); // the previous round's W / Y are consumed (first round: sE, sF are visible)
+        if (!ragged) {
 #pragma unroll
-        for (int j = 0; j < SRK_GRP_PRE; ++j)
-            if (qpos[j] < nb * nf) sW[loff[j]] = pre[j];
+            for (int j = 0; j < SRK_GRP_PRE; ++j)
+                if (qpos[j] < nq) sW[loff[j]] = pre[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < SRK_GRP_PRE; ++j)
+                if (qpos[j] < nq) sW[pdst[j]] = pre[j];
+            if (tid < nb) sM[tid] = pmask;
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < YI; ++i) {
             if (ypl[i] >= nb) continue;
+            double* wp = sW + ywo[i];
+            double* yp = sY + yyo[i];
+            if (ragged && !((sM[ypl[i]] >> ya[i]) & 1u)) { // this landmark does not see this frame: zero blocks
+                wp[0] = wp[12] = wp[24] = 0.0;
+                yp[0] = yp[10] = yp[20] = 0.0;
+                continue;
+            }
             const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl[i]]); // rows are 96 B: 16-byte aligned
             const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
-            const double* wp = sW + ywo[i];
             const double w0 = wp[0], w1 = wp[12], w2 = wp[24];
-            double* yp = sY + yyo[i];
             yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
             yp[10] = e23.y * w0 + e45.x * w1 + e45.y * w2;
             yp[20] = e67.x * w0 + e67.y * w1 + e89.x * w2;
             racc[i] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
         }
-        if (pb + SRK_GRP_PB < np) prefetch(pb + SRK_GRP_PB); // in flight while this round is multiplied
+        if (pb + SRK_GRP_PB < np) nq_next = prefetch(pb + SRK_GRP_PB); // in flight while this round is multiplied
         __syncthreads();
         for (int pl = 0; pl < nb; ++pl) {
             const double* w = sW + pl * W_LM;
@@ -798,17 +831,18 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     }
 }
 
-void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr,
-                              const int32_t* obs_frame, const double* W, const double* Vg, double* S, double* rhs,
-                              const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups, int64_t n_wide)
+void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
+                              const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
+                              double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
+                              const int32_t* grp_frames, int64_t n_groups, int64_t n_wide)
 {
     if (n_groups <= 0) return;
     if (n_wide < n_groups)
-        hipLaunchKernelGGL(k_schur_grouped<1>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr,
-                           obs_frame, W, Vg, S, rhs, grp_first, grp_count);
+        hipLaunchKernelGGL(k_schur_grouped<1>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr, obs_pt,
+                           obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames);
     if (n_wide > 0) // runs with more than SRK_GRP_NF1 frames: two half blocks per thread
-        hipLaunchKernelGGL(k_schur_grouped<2>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr,
-                           obs_frame, W, Vg, S, rhs, grp_first, grp_count);
+        hipLaunchKernelGGL(k_schur_grouped<2>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr, obs_pt,
+                           obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames);
 }
 
 // G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark

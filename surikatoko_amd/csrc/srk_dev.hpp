@@ -53,9 +53,12 @@ void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* 
 #define SRK_GRP_MAXNF_HOST 24   // must match SRK_GRP_MAXNF in srk_ba_kernels.hip
 #define SRK_GRP_MAXPTS_HOST 128 // landmarks per workgroup run
 #define SRK_GRP_NF1_HOST 21     // must match SRK_GRP_NF1
-void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr,
-                              const int32_t* obs_frame, const double* W, const double* Vg, double* S, double* rhs,
-                              const int32_t* grp_first, const int32_t* grp_count, int64_t n_groups,
+void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
+                              const uint8_t* obs_slot /* [O] slot of the observation's frame in its run's frame set */,
+                              const uint32_t* pt_mask /* [N] slots a landmark sees */, const double* W, const double* Vg,
+                              double* S, double* rhs, const int32_t* grp_first, const int32_t* grp_count,
+                              const int32_t* grp_nf /* size of the run's frame set; negative = ragged run */,
+                              const int32_t* grp_frames /* [n_groups][SRK_GRP_MAXNF_HOST] */, int64_t n_groups,
                               int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
                          double ident /* diagonal of fixed / padding variables */);

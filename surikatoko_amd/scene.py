@@ -66,3 +66,25 @@ def generate_scene(spec: SceneSpec, with_gt=False):
     if with_gt:
         return sc, pts_gt, Rg, Tg
     return sc
+
+
+def drop_observations(scene, fraction, seed=0, keep_min=2):
+    """A copy of `scene` with about `fraction` of its observations removed at random (every landmark keeps at least
+    `keep_min`, its first and last ones among them): ragged tracks as a feature tracker produces them, where hardly any
+    two landmarks see exactly the same frames."""
+    import numpy as np
+    from .ba import Scene
+    rng = np.random.RandomState(seed)
+    keep = rng.rand(scene.O) >= fraction
+    rp = scene.row_ptr
+    for i in range(scene.N):
+        lo, hi = int(rp[i]), int(rp[i + 1])
+        if hi - lo <= keep_min:
+            keep[lo:hi] = True
+        else:
+            keep[lo] = keep[hi - 1] = True
+    counts = np.add.reduceat(keep.astype(np.int64), rp[:-1]) if scene.N else np.zeros(0, np.int64)
+    counts[rp[:-1] == rp[1:]] = 0
+    new_rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return Scene(scene.points, scene.cam_R, scene.cam_T, scene.K, scene.shared_k, new_rp, scene.obs_frame[keep],
+                 scene.obs_uv[keep])

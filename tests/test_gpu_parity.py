@@ -104,7 +104,8 @@ def _check(out, M, corr_tol=1e-8):
         assert row[f] == 1.0
         row[f] = 0
         assert np.all(row == 0) and out["rhs_g"][f] == 0
-    assert out["ok_g"] and out["ok_o"]
+    assert out["ok_o"], "oracle solve failed"
+    assert out["ok_g"], "GPU solve failed"
     # Cholesky (GPU) vs Householder QR (oracle, as in the reference) on the same system.  QR on the unscaled system
     # loses digits when intrinsics and pose variables live on very different scales (cond ~1e14 on some scenes),
     # so the yardstick is the exact solution of the ORACLE's system (iterative refinement in long double):
@@ -176,6 +177,37 @@ def test_phases_on_synthetic_scenes(orc, gpu, name, c):
     sc = sa.generate_scene(SCENES[name])
     out = _phases(orc, gpu, sc, SCENES[name].f0, c)
     _check(out, sc.M, corr_tol=1e-7)
+
+
+RAGGED = {
+    # ragged feature tracks: observations dropped at random, so that hardly two landmarks see the same frames and the
+    # grouped Schur kernel works on unions of frame lists (zero blocks where a landmark misses a frame of its run)
+    "ragged_short": (sa.SceneSpec(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7), 0.25),
+    "ragged_20": (sa.SceneSpec(n_frames=60, grid_nx=40, grid_ny=30, vis_window=20, noise_uv_pix=0.3), 0.15),  # unions reach 21
+    "ragged_wide": (sa.SceneSpec(n_frames=50, grid_nx=24, grid_ny=20, vis_window=23), 0.10),            # 22..24 frames: two half blocks per thread
+    "ragged_long": (sa.SceneSpec(n_frames=60, grid_nx=12, grid_ny=10, vis_window=40), 0.30),              # > 24 frames: per-landmark kernel
+}
+
+
+@pytest.mark.parametrize("name", list(RAGGED))
+@pytest.mark.parametrize("c", [1e-4, 10.0])
+def test_phases_on_ragged_tracks(orc, gpu, name, c):
+    spec, frac = RAGGED[name]
+    sc = sa.drop_observations(sa.generate_scene(spec), frac, seed=7)
+    lists = {sc.obs_frame[sc.row_ptr[i]:sc.row_ptr[i + 1]].tobytes() for i in range(sc.N)}
+    assert len(lists) > sc.N // 4  # really ragged
+    out = _phases(orc, gpu, sc, spec.f0, c)
+    _check(out, sc.M, corr_tol=1e-7)
+
+
+def test_ragged_tracks_end_to_end(orc, gpu):
+    spec, frac = RAGGED["ragged_20"]
+    sc = sa.drop_observations(sa.generate_scene(spec), frac, seed=3)
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, allowed=1e-7, max_factor=1e6, max_iterations=5)
+    assert ok == (rc_o == 0)
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6)
+    assert np.abs(sg.points - so.points).max() < 1e-6
 
 
 def test_singular_point_blocks_are_skipped(orc, gpu):
