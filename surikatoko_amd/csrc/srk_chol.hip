@@ -816,14 +816,32 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
 // same as one Cholesky of a re-ordered matrix; the dependency chain is n / P + sepw (P - 1) pivots instead of n.
 // No atomics and a fixed summation order: results are bit-reproducible.
 
-// one workgroup per local row of a chunk matrix; blockIdx.z = chunk
-__global__ __launch_bounds__(256) void k_chunk_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
+// Level set-up in one launch.  blockIdx.z < P: one workgroup per local row of chunk z's matrix.  blockIdx.z == P: one
+// workgroup per row of the separator system Cs (block diagonal part from S, ws from rhs); only its block tridiagonal
+// band is ever written by the factorisation (and read by a child plan's gather), everything outside it stays the
+// zero it was allocated with.
+__global__ __launch_bounds__(256) void k_level_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
                                                       const int64_t* __restrict__ env_col, const CholBatch B,
-                                                      const CholStep first, int64_t sepw, int P)
+                                                      const CholStep first, int64_t sepw, int P,
+                                                      const int64_t* __restrict__ sep_start, double* __restrict__ Cs,
+                                                      int64_t lds, double* __restrict__ ws)
 {
     const int z = blockIdx.z;
-    const int64_t ldc = B.it[z].ld, nc = B.it[z].ncols, a = first.v[z];
     const int64_t i = blockIdx.x;
+    if (z == P) {
+        if (i >= lds) return;
+        const int64_t c = i / sepw, u = i - c * sepw;
+        const int64_t g = sep_start[c] + u;
+        double* dst = Cs + i * lds;
+        const int64_t j0 = c > 0 ? (c - 1) * sepw : 0, j1 = (c + 1) * sepw; // lower part of the band
+        for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+            int64_t cj = j / sepw, v = j - cj * sepw;
+            dst[j] = (cj == c && v <= u) ? S[g * ld + sep_start[c] + v] : 0.0;
+        }
+        if (threadIdx.x == 0) ws[i] = rhs[g];
+        return;
+    }
+    const int64_t ldc = B.it[z].ld, nc = B.it[z].ncols, a = first.v[z];
     if (i >= ldc) return;
     const bool has_top = z > 0, has_bot = z < P - 1;
     double* __restrict__ wc = B.it[z].w;
@@ -853,55 +871,24 @@ __global__ __launch_bounds__(256) void k_chunk_gather(const double* __restrict__
     if (threadIdx.x == 0) wc[i] = 0.0;
 }
 
-// separator system: Cs (lds x lds) block diagonal part from S, ws from rhs.  Only the block tridiagonal band is ever
-// written by the factorisation (and read by a child plan's gather); everything outside it stays the zero it was
-// allocated with.
-__global__ __launch_bounds__(256) void k_sep_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
-                                                    const int64_t* __restrict__ sep_start, int64_t sepw,
-                                                    double* __restrict__ Cs, int64_t lds, double* __restrict__ ws)
+// Add the chunks' border blocks (-Y Y^T) and border right-hand sides into the separator system: one workgroup per
+// separator row.  Separator c lies between chunks c and c + 1: its diagonal block takes chunk c's (below, below)
+// block and chunk c + 1's (above, above) block, its coupling to separator c - 1 is chunk c's (below, above) block.
+// Fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void k_sep_reduce(const CholBatch B, int64_t sepw, double* __restrict__ Cs, int64_t lds,
+                                                    double* __restrict__ ws)
 {
-    const int64_t i = blockIdx.x; // row of Cs
-    const int64_t c = i / sepw, u = i - c * sepw;
-    const int64_t g = sep_start[c] + u;
-    double* dst = Cs + i * lds;
-    const int64_t j0 = c > 0 ? (c - 1) * sepw : 0, j1 = (c + 1) * sepw; // lower part of the band
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
-        int64_t cj = j / sepw, v = j - cj * sepw;
-        dst[j] = (cj == c && v <= u) ? S[g * ld + sep_start[c] + v] : 0.0;
-    }
-    if (threadIdx.x == 0) ws[i] = rhs[g];
-}
-
-// add the chunks' border blocks (-Y Y^T) and border right-hand sides into the separator system.  Chunk c touches
-// separators c-1 and c, so the chunks of one parity touch disjoint entries: two launches (even, odd), no atomics.
-__global__ __launch_bounds__(256) void k_sep_reduce(const CholBatch B, int parity, int P, int64_t sepw,
-                                                    double* __restrict__ Cs, int64_t lds, double* __restrict__ ws)
-{
-    const int c = 2 * (int)blockIdx.z + parity;
-    if (c >= P) return;
-    const int64_t top_sep = c > 0 ? c - 1 : -1, bot_sep = c < P - 1 ? c : -1;
-    const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;
-    const double* __restrict__ Ac = B.it[c].A;
-    const int64_t u2 = blockIdx.x; // border row 0 .. 2 sepw - 1
-    const int64_t su = u2 < sepw ? top_sep : bot_sep;
-    if (su < 0) return;
-    const int64_t ru = su * sepw + (u2 < sepw ? u2 : u2 - sepw);
-    const double* src = Ac + (nc + u2) * ldc + nc;
-    for (int64_t v2 = threadIdx.x; v2 <= u2; v2 += 256) {
-        const int64_t sv = v2 < sepw ? top_sep : bot_sep;
-        if (sv < 0) continue;
-        const int64_t cv = sv * sepw + (v2 < sepw ? v2 : v2 - sepw);
-        Cs[ru * lds + cv] += src[v2];
-    }
-    if (threadIdx.x == 0) ws[ru] += B.it[c].w[nc + u2];
-}
-
-// separator part of the global solution
-__global__ __launch_bounds__(256) void k_sep_scatter(int64_t n, int64_t sepw, const int64_t* __restrict__ sep_start,
-                                                     const double* __restrict__ xs, double* __restrict__ x)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) x[sep_start[i / sepw] + i % sepw] = xs[i];
+    const int64_t ru = blockIdx.x;
+    const int c = (int)(ru / sepw);
+    const int64_t u = ru - (int64_t)c * sepw;
+    const int64_t n0 = B.it[c].ncols, l0 = B.it[c].ld, n1 = B.it[c + 1].ncols, l1 = B.it[c + 1].ld;
+    const double* below = B.it[c].A + (n0 + sepw + u) * l0 + n0;   // chunk c, border row sepw + u: [above | below]
+    const double* above = B.it[c + 1].A + (n1 + u) * l1 + n1;       // chunk c + 1, border row u: [above]
+    double* row = Cs + ru * lds;
+    for (int64_t v = threadIdx.x; v <= u; v += 256) row[c * sepw + v] = (row[c * sepw + v] + below[sepw + v]) + above[v];
+    if (c > 0)
+        for (int64_t v = threadIdx.x; v < sepw; v += 256) row[(c - 1) * sepw + v] += below[v];
+    if (threadIdx.x == 0) ws[ru] = (ws[ru] + B.it[c].w[n0 + sepw + u]) + B.it[c + 1].w[n1 + u];
 }
 
 // border part of a chunk's solution = the separator solution; fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i].
@@ -931,10 +918,16 @@ __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, in
     if (wave == 0) B.it[c].y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
-// interior part of the global solution
-__global__ __launch_bounds__(256) void k_chunk_scatter(const CholBatch B, const CholStep first, double* __restrict__ x)
+// the level's solution: chunk interiors (blockIdx.z < P) and separator variables (blockIdx.z == P)
+__global__ __launch_bounds__(256) void k_level_scatter(const CholBatch B, const CholStep first, int P, int64_t sepw,
+                                                       const int64_t* __restrict__ sep_start, const double* __restrict__ xs,
+                                                       int64_t lds, double* __restrict__ x)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.z == P) {
+        if (j < lds) x[sep_start[j / sepw] + j % sepw] = xs[j];
+        return;
+    }
     if (j < B.it[blockIdx.z].ncols) x[first.v[blockIdx.z] + j] = B.it[blockIdx.z].x[j];
 }
 
@@ -956,27 +949,21 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
         max_nc = std::max(max_nc, pl.n[c]);
     }
     Bs.it[0] = CholItem{ pl.Cs, pl.ws, pl.ys, pl.xs, pl.dinvs, lds, lds, lds, lds };
-    const unsigned cblocks = (unsigned)((max_nc + 255) / 256);
 
-    LAUNCH(k_chunk_gather, dim3((unsigned)max_ldc, 1, (unsigned)P), dim3(256), 0, s, S, ld, rhs, d_env_col, B,
-                       first, sepw, P);
-    LAUNCH(k_sep_gather, dim3((unsigned)lds), dim3(256), 0, s, S, ld, rhs, pl.d_sep_start, sepw, pl.Cs, lds,
-                       pl.ws);
+    LAUNCH(k_level_gather, dim3((unsigned)std::max(max_ldc, lds), 1, (unsigned)(P + 1)), dim3(256), 0, s, S, ld, rhs,
+           d_env_col, B, first, sepw, P, pl.d_sep_start, pl.Cs, lds, pl.ws);
     chol_factor(s, B, P, H, d_info, prof);
-    for (int parity = 0; parity < 2; ++parity)
-        LAUNCH(k_sep_reduce, dim3((unsigned)(2 * sepw), 1, (unsigned)((P + 1) / 2)), dim3(256), 0, s, B, parity,
-                           P, sepw, pl.Cs, lds, pl.ws);
+    LAUNCH(k_sep_reduce, dim3((unsigned)lds), dim3(256), 0, s, B, sepw, pl.Cs, lds, pl.ws);
     if (pl.child) { // the separator system is block tridiagonal: chunk it again
         solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof);
     } else {
         chol_factor(s, Bs, 1, &Hs, d_info, prof);
         chol_bwd(s, Bs, 1, &Hs, prof);
     }
-    LAUNCH(k_sep_scatter, dim3((unsigned)((lds + 255) / 256)), dim3(256), 0, s, lds, sepw, pl.d_sep_start,
-                       pl.xs, x);
     LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
     chol_bwd(s, B, P, H, prof);
-    LAUNCH(k_chunk_scatter, dim3(cblocks, 1, (unsigned)P), dim3(256), 0, s, B, first, x);
+    LAUNCH(k_level_scatter, dim3((unsigned)((std::max(max_nc, lds) + 255) / 256), 1, (unsigned)(P + 1)), dim3(256), 0, s, B,
+           first, P, sepw, pl.d_sep_start, pl.xs, lds, x);
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,

@@ -16,9 +16,9 @@ def run(rank, world, port, out_dir, spec_kwargs, iters):
     from surikatoko_amd.ba import covisibility, revert_normalization
     from surikatoko_amd.dist import make_allreduce_hook
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # file rendezvous inside the test's own directory: no TCP port to race for (`port` is kept for the signature)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                            init_method="file://" + os.path.join(out_dir, "rendezvous"))
     try:
         spec = sa.SceneSpec(**spec_kwargs)
         full = sa.generate_scene(spec)
@@ -33,6 +33,8 @@ def run(rank, world, port, out_dir, spec_kwargs, iters):
         crit = sa.BundleAdjustmentKanataniTermCriteria()
         crit.AllowedReprojErrRelativeChange(1e-7)
         ok = ba.optimize(crit, iters)
+        print(f"rank {rank}: iterations {ba.report.iterations} attempts {ba.report.attempts} err {ba.report.err_initial!r} -> "
+              f"{ba.report.err_final!r} status {ba.report.status}", flush=True)
         out = shard.copy()
         ba.download(out, revert_normalization=False)
         revert_normalization(out, nrm)

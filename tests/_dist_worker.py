@@ -19,9 +19,9 @@ def run(rank, world, port, out_dir):
     from surikatoko_amd.dist import make_allreduce_hook
     from oracle import oracle as orc
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # file rendezvous inside the test's own directory: no TCP port to race for (`port` is kept for the signature)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                            init_method="file://" + os.path.join(out_dir, "rendezvous"))
     try:
         spec = sa.SceneSpec(n_frames=14, grid_nx=13, grid_ny=9, vis_window=5)
         full = sa.generate_scene(spec)

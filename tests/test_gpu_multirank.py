@@ -34,7 +34,7 @@ def _free_port():
 def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs):
     import torch.multiprocessing as mp
     import _dist_gpu_worker
-    iters = 4
+    iters = 3  # far from convergence: no accept / reject decision is a near tie that summation order could flip
     spec = sa.SceneSpec(**spec_kwargs)
     ref = sa.generate_scene(spec)
     ba = sa.BundleAdjustmentKanatani(0)
@@ -51,13 +51,15 @@ def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs):
     for r in range(world):
         z = res[r]
         assert bool(z["ok"]) == ok_ref
-        assert (int(z["iterations"]), int(z["attempts"]), int(z["seen"]), int(z["status"])) == \
-               (ref_rep[0], ref_rep[1], ref_rep[4], ref_rep[5])
+        got = (int(z["iterations"]), int(z["attempts"]), int(z["seen"]), int(z["status"]))
+        assert got == (ref_rep[0], ref_rep[1], ref_rep[4], ref_rep[5]), (r, got, ref_rep, float(z["err_final"]))
         assert float(z["err_initial"]) == pytest.approx(ref_rep[2], rel=1e-12)
         assert float(z["err_final"]) == pytest.approx(ref_rep[3], rel=1e-8)
         # every rank solved the same all-reduced system with the same deterministic solver
-        assert np.array_equal(z["cam_R"], res[0]["cam_R"]) and np.array_equal(z["cam_T"], res[0]["cam_T"])
-        assert np.abs(z["cam_T"] - ref.cam_T).max() < 1e-7 and np.abs(z["cam_R"] - ref.cam_R).max() < 1e-7
+        assert np.array_equal(z["cam_R"], res[0]["cam_R"]) and np.array_equal(z["cam_T"], res[0]["cam_T"]), \
+            (r, float(np.abs(z["cam_T"] - res[0]["cam_T"]).max()))
+        dT, dR = float(np.abs(z["cam_T"] - ref.cam_T).max()), float(np.abs(z["cam_R"] - ref.cam_R).max())
+        assert dT < 1e-7 and dR < 1e-7, (r, dT, dR)
         lo, hi = int(z["lo"]), int(z["hi"])
         assert np.abs(z["points"] - ref.points[lo:hi]).max() < 1e-7
         if r:
