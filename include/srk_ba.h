@@ -132,6 +132,24 @@ int srk_ba_reproj_error_mvf(srk_ba*, double f0,
                             const int64_t* obs_row_ptr, const int32_t* obs_frame, const double* obs_uv,
                             double z_tol, double* reproj_err, int64_t* summands /* may be NULL */);
 
+/* ---- multi-view-factorization steps (the caller on the other side of the BA path) ----
+ * Estimate3DPointDepthFromFrames (multi-view-factorization.cpp:223-253, MASKS 8.44), batched over tracks: track i has
+ * observations [row_ptr[i], row_ptr[i+1]) = (frame, metric homogeneous image point); its FIRST observation is the
+ * base frame (:195-215) and depth_out[i] is the depth in that frame (NaN for tracks with fewer than 2 observations).
+ * cam_R / cam_T: world -> camera of every frame. */
+int srk_mvf_estimate_depths(srk_ba*, int64_t n_tracks, const int64_t* row_ptr, const int32_t* frame,
+                            const double* x_meter /* [O][3] */, int32_t n_frames, const double* cam_R, const double* cam_T,
+                            double* depth_out /* [n_tracks] */);
+/* FindRelativeMotionMultiPoints (:107-189) + ProjectOntoSO3 (:79-104): camera motion anchor -> target from the common
+ * points' homogeneous image coordinates in both frames and their depths in the anchor frame.  The Gram matrix of the
+ * 3P x 12 system is reduced on the device; its smallest eigenvector replaces the reference's JacobiSVD (same vector up
+ * to sign, and the projection is sign-invariant).  At least 6 points (each gives two independent equations of the 11
+ * needed).  Returns 1 ok, 0 = projection failed (det S ~ 0), negative = error. */
+int srk_mvf_relative_motion(srk_ba*, int64_t n_points, const double* x_anchor /* [P][3] */, const double* x_target /* [P][3] */,
+                            const double* depth_anchor /* [P] */, double* R_out /* [9] row-major */, double* T_out /* [3] */);
+/* ProjectOntoSO3 alone (host code, no GPU needed): 1 ok, 0 = det S ~ 0 */
+int srk_mvf_project_onto_so3(const double* R_noisy, const double* T_noisy, double* R_out, double* T_out);
+
 /* host-side gauge normalisation (bundle-adj-kanatani.cpp:203-270); no GPU needed */
 int srk_ba_normalize_scene(int64_t n_points, double* points_xyz, int32_t n_frames, double* cam_R, double* cam_T,
                            double t1y, int32_t unity_comp_ind, srk_ba_normalizer* out); /* 1 = ok, 0 = failed */

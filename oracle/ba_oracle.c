@@ -511,6 +511,134 @@ int orc_reproj_error_mvf(double f0, int64_t N, const double* points, int32_t M, 
     return 1;
 }
 
+/* ---------------------------------------------------------------- multi-view-factorization steps
+ * The reference computes these with Eigen::JacobiSVD (an un-vendored dependency); the restatement uses a one-sided
+ * (Hestenes) Jacobi SVD, which yields the same singular vectors up to sign -- and ProjectOntoSO3 is sign-invariant. */
+
+/* one-sided Jacobi SVD of A (m x n, row-major, m >= n): A is overwritten by U*diag(s) column-wise, V (n x n row-major)
+ * accumulates the rotations; singular values = column norms (unsorted). */
+static void svd_hestenes(int64_t m, int n, double* A, double* V, double* sv)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double a = 0, b = 0, c = 0;
+                for (int64_t i = 0; i < m; ++i) {
+                    double x = A[i * n + p], y = A[i * n + q];
+                    a += x * x; b += y * y; c += x * y;
+                }
+                if (c == 0) continue;
+                double lim = sqrt(a * b);
+                if (fabs(c) <= 1e-300 + 1e-17 * lim) continue;
+                if (fabs(c) / (lim > 0 ? lim : 1) > off) off = fabs(c) / (lim > 0 ? lim : 1);
+                double zeta = (b - a) / (2 * c);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                double cs = 1 / sqrt(1 + t * t), sn = cs * t;
+                for (int64_t i = 0; i < m; ++i) {
+                    double x = A[i * n + p], y = A[i * n + q];
+                    A[i * n + p] = cs * x - sn * y;
+                    A[i * n + q] = sn * x + cs * y;
+                }
+                for (int i = 0; i < n; ++i) {
+                    double x = V[i * n + p], y = V[i * n + q];
+                    V[i * n + p] = cs * x - sn * y;
+                    V[i * n + q] = sn * x + cs * y;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    for (int j = 0; j < n; ++j) {
+        double a = 0;
+        for (int64_t i = 0; i < m; ++i) a += A[i * n + j] * A[i * n + j];
+        sv[j] = sqrt(a);
+    }
+}
+
+/* multi-view-factorization.cpp:79-104 ProjectOntoSO3 (MASKS 8.41, 8.42).  R row-major.  returns 0 when det S ~ 0 */
+int orc_project_onto_so3(const double R_noisy[9], const double T_noisy[3], double R_out[9], double T_out[3])
+{
+    double A[9], V[9], sv[3], U[9];
+    memcpy(A, R_noisy, sizeof A);
+    svd_hestenes(3, 3, A, V, sv);
+    double det_S = sv[0] * sv[1] * sv[2];
+    if (ISCLOSE_DEF(0, det_S)) return 0; /* :88-89 */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) U[3 * i + j] = A[3 * i + j] / sv[j];
+    double ng[9]; /* U V^T */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) ng[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+    double det = ng[0] * (ng[4] * ng[8] - ng[5] * ng[7]) - ng[1] * (ng[3] * ng[8] - ng[5] * ng[6]) +
+                 ng[2] * (ng[3] * ng[7] - ng[4] * ng[6]);
+    int sign = det >= 0 ? 1 : -1; /* approx-alg.h:41 */
+    for (int i = 0; i < 9; ++i) R_out[i] = sign * ng[i];
+    double s = sign / cbrt(det_S);
+    for (int i = 0; i < 3; ++i) T_out[i] = s * T_noisy[i];
+    return 1;
+}
+
+/* multi-view-factorization.cpp:107-189 FindRelativeMotionMultiPoints: rows [x2]x (kron(x1^T, I) | alpha I) of the
+ * 3P x 12 system, r_and_t = right singular vector of the smallest singular value (vec(R) column-major, then T),
+ * then ProjectOntoSO3.  x_anchor / x_target: homogeneous image coordinates [P][3]. */
+int orc_mvf_relative_motion(int64_t P, const double* x_anchor, const double* x_target, const double* depth_anchor,
+                            double R_out[9], double T_out[3])
+{
+    if (P < 6) return 0; /* 2 independent equations per point, 11 needed */
+    double* A = (double*)calloc((size_t)(3 * P * 12), sizeof(double));
+    for (int64_t i = 0; i < P; ++i) {
+        const double* c1 = x_anchor + 3 * i;
+        const double* c2 = x_target + 3 * i;
+        double sk[9] = { 0, -c2[2], c2[1], c2[2], 0, -c2[0], -c2[1], c2[0], 0 }; /* obs-geom.cpp:512-518 */
+        double alpha = 1 / depth_anchor[i];
+        for (int r = 0; r < 3; ++r) {
+            double* row = A + (3 * i + r) * 12;
+            for (int comp = 0; comp < 3; ++comp)
+                for (int cc = 0; cc < 3; ++cc) row[3 * comp + cc] = c1[comp] * sk[3 * r + cc];
+            for (int cc = 0; cc < 3; ++cc) row[9 + cc] = alpha * sk[3 * r + cc];
+        }
+    }
+    double V[144], sv[12];
+    svd_hestenes(3 * P, 12, A, V, sv);
+    free(A);
+    int jmin = 0;
+    for (int j = 1; j < 12; ++j)
+        if (sv[j] < sv[jmin]) jmin = j;
+    double Rn[9], Tn[3];
+    for (int col = 0; col < 3; ++col) /* column-major vec(R) (:174) */
+        for (int row = 0; row < 3; ++row) Rn[3 * row + col] = V[(3 * col + row) * 12 + jmin];
+    for (int i = 0; i < 3; ++i) Tn[i] = V[(9 + i) * 12 + jmin];
+    return orc_project_onto_so3(Rn, Tn, R_out, T_out);
+}
+
+/* multi-view-factorization.cpp:223-253 Estimate3DPointDepthFromFrames (MASKS 8.44) for ONE track: observation 0 is
+ * the base frame; frame_from_base = SE3AFromB(frame_i_from_world, base_from_world) (:205-213, obs-geom.cpp:147-150). */
+double orc_mvf_point_depth(int64_t n_obs, const int32_t* frame, const double* x_meter, const double* cam_R,
+                           const double* cam_T)
+{
+    const double* Rb = cam_R + 9 * frame[0];
+    const double* Tb = cam_T + 3 * frame[0];
+    const double* x1 = x_meter;
+    double num = 0, den = 0;
+    for (int64_t i = 1; i < n_obs; ++i) {
+        const double* Ri = cam_R + 9 * frame[i];
+        const double* Ti = cam_T + 3 * frame[i];
+        const double* xi = x_meter + 3 * i;
+        double Rr[9], Tr[3], v[3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Rr[3 * a + b] = Ri[3 * a] * Rb[3 * b] + Ri[3 * a + 1] * Rb[3 * b + 1] + Ri[3 * a + 2] * Rb[3 * b + 2];
+        for (int a = 0; a < 3; ++a) Tr[a] = Ti[a] - (Rr[3 * a] * Tb[0] + Rr[3 * a + 1] * Tb[1] + Rr[3 * a + 2] * Tb[2]);
+        for (int a = 0; a < 3; ++a) v[a] = Rr[3 * a] * x1[0] + Rr[3 * a + 1] * x1[1] + Rr[3 * a + 2] * x1[2];
+        double h1[3] = { xi[1] * Tr[2] - xi[2] * Tr[1], xi[2] * Tr[0] - xi[0] * Tr[2], xi[0] * Tr[1] - xi[1] * Tr[0] };
+        double h2[3] = { xi[1] * v[2] - xi[2] * v[1], xi[2] * v[0] - xi[0] * v[2], xi[0] * v[1] - xi[1] * v[0] };
+        num += h1[0] * h2[0] + h1[1] * h2[1] + h1[2] * h2[2];
+        den += h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2];
+    }
+    double alpha = -num / den;
+    return 1 / alpha;
+}
+
 /* ---------------------------------------------------------------- derivatives */
 
 /* BA:1528-1537 FirstDerivFromPqrDerivative (formula 8) */

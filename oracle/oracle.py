@@ -93,6 +93,40 @@ class Scene:
                 C.c_int32(self.shared_k), _i64(self.row_ptr), _i32(self.obs_frame), _d(self.obs_uv))
 
 
+def project_onto_so3(R_noisy, T_noisy):
+    """(ok, R, T) of ProjectOntoSO3 (multi-view-factorization.cpp:79-104); R row-major 3x3."""
+    Rn = np.ascontiguousarray(R_noisy, dtype=np.float64).reshape(9)
+    Tn = np.ascontiguousarray(T_noisy, dtype=np.float64).reshape(3)
+    R, T = np.zeros(9), np.zeros(3)
+    f = lib().orc_project_onto_so3
+    f.restype = C.c_int
+    ok = f(_d(Rn), _d(Tn), _d(R), _d(T))
+    return bool(ok), R.reshape(3, 3), T
+
+
+def mvf_relative_motion(x_anchor, x_target, depth_anchor):
+    """(ok, R, T) of FindRelativeMotionMultiPoints (multi-view-factorization.cpp:107-189)."""
+    xa = np.ascontiguousarray(x_anchor, dtype=np.float64).reshape(-1, 3)
+    xt = np.ascontiguousarray(x_target, dtype=np.float64).reshape(-1, 3)
+    dp = np.ascontiguousarray(depth_anchor, dtype=np.float64).reshape(-1)
+    R, T = np.zeros(9), np.zeros(3)
+    f = lib().orc_mvf_relative_motion
+    f.restype = C.c_int
+    ok = f(C.c_int64(xa.shape[0]), _d(xa), _d(xt), _d(dp), _d(R), _d(T))
+    return bool(ok), R.reshape(3, 3), T
+
+
+def mvf_point_depth(frame, x_meter, cam_R, cam_T):
+    """Estimate3DPointDepthFromFrames (multi-view-factorization.cpp:223-253) for one track."""
+    fr = np.ascontiguousarray(frame, dtype=np.int32)
+    xm = np.ascontiguousarray(x_meter, dtype=np.float64).reshape(-1, 3)
+    R = np.ascontiguousarray(cam_R, dtype=np.float64).reshape(-1, 9)
+    T = np.ascontiguousarray(cam_T, dtype=np.float64).reshape(-1, 3)
+    f = lib().orc_mvf_point_depth
+    f.restype = C.c_double
+    return float(f(C.c_int64(fr.shape[0]), _i32(fr), _d(xm), _d(R), _d(T)))
+
+
 def reproj_error_mvf(f0, sc):
     """(ok, err, summands) of MultiViewIterativeFactorizer::ReprojError (multi-view-factorization.cpp:415-475)."""
     e, n = C.c_double(0), C.c_int64(0)

@@ -1243,6 +1243,166 @@ int srk_ba_reproj_error_mvf(srk_ba* h, double f0, int64_t N, const double* pts, 
     return 1;
 }
 
+// ------------------------------------------------------------------ multi-view-factorization steps
+namespace {
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed): V's columns = eigenvectors
+void jacobi_eig(int n, double* A, double* V, double* ev)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; ++i) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-34 * diag || off == 0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p * n + q];
+                if (apq == 0) continue;
+                double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(1 + theta * theta));
+                double c = 1 / std::sqrt(1 + t * t), sn = c * t;
+                for (int k = 0; k < n; ++k) { // columns p, q
+                    double x = A[k * n + p], y = A[k * n + q];
+                    A[k * n + p] = c * x - sn * y;
+                    A[k * n + q] = sn * x + c * y;
+                }
+                for (int k = 0; k < n; ++k) { // rows p, q
+                    double x = A[p * n + k], y = A[q * n + k];
+                    A[p * n + k] = c * x - sn * y;
+                    A[q * n + k] = sn * x + c * y;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double x = V[k * n + p], y = V[k * n + q];
+                    V[k * n + p] = c * x - sn * y;
+                    V[k * n + q] = sn * x + c * y;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) ev[i] = A[i * n + i];
+}
+
+// ProjectOntoSO3 (multi-view-factorization.cpp:79-104; MASKS 8.41, 8.42): R = sign(det(U V^T)) U V^T from the SVD of
+// the noisy R (via the eigen-decomposition of R^T R), T scaled by sign / cbrt(det S).  false when det S ~ 0.
+bool project_onto_so3(const double Rn[9], const double Tn[3], double R[9], double T[3])
+{
+    double G[9], V[9], ev[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G[3 * i + j] = Rn[i] * Rn[j] + Rn[3 + i] * Rn[3 + j] + Rn[6 + i] * Rn[6 + j];
+    jacobi_eig(3, G, V, ev);
+    double sv[3];
+    for (int k = 0; k < 3; ++k) sv[k] = std::sqrt(std::max(ev[k], 0.0));
+    double det_S = sv[0] * sv[1] * sv[2];
+    if (srk::is_close(0.0, det_S)) return false; // :88-89
+    double U[9]; // U = R V S^-1
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) U[3 * i + k] = (Rn[3 * i] * V[k] + Rn[3 * i + 1] * V[3 + k] + Rn[3 * i + 2] * V[6 + k]) / sv[k];
+    double ng[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) ng[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+    double det = ng[0] * (ng[4] * ng[8] - ng[5] * ng[7]) - ng[1] * (ng[3] * ng[8] - ng[5] * ng[6]) +
+                 ng[2] * (ng[3] * ng[7] - ng[4] * ng[6]);
+    int sign = det >= 0 ? 1 : -1; // approx-alg.h:41
+    for (int i = 0; i < 9; ++i) R[i] = sign * ng[i];
+    double sc = sign / std::cbrt(det_S);
+    for (int i = 0; i < 3; ++i) T[i] = sc * Tn[i];
+    return true;
+}
+} // namespace
+
+extern "C" int srk_mvf_project_onto_so3(const double* R_noisy, const double* T_noisy, double* R_out, double* T_out)
+{
+    if (!R_noisy || !T_noisy || !R_out || !T_out) return SRK_E_ARGS;
+    return project_onto_so3(R_noisy, T_noisy, R_out, T_out) ? 1 : 0;
+}
+
+extern "C" int srk_mvf_estimate_depths(srk_ba* h, int64_t n_tracks, const int64_t* row_ptr, const int32_t* frame,
+                                       const double* x_meter, int32_t n_frames, const double* cam_R, const double* cam_T,
+                                       double* depth_out)
+{
+    if (!h) return SRK_E_ARGS;
+    if (n_tracks < 0 || n_frames < 1 || !row_ptr || !cam_R || !cam_T || (n_tracks > 0 && !depth_out) || row_ptr[0] != 0) {
+        h->last_error = "srk_mvf_estimate_depths: bad arguments";
+        return SRK_E_ARGS;
+    }
+    const int64_t O = row_ptr[n_tracks];
+    if (O > 0 && (!frame || !x_meter)) { h->last_error = "srk_mvf_estimate_depths: null observation arrays"; return SRK_E_ARGS; }
+    for (int64_t i = 0; i < n_tracks; ++i) {
+        if (row_ptr[i + 1] < row_ptr[i]) { h->last_error = "row_ptr not monotone"; return SRK_E_ARGS; }
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o)
+            if (frame[o] < 0 || frame[o] >= n_frames) { h->last_error = "frame out of range"; return SRK_E_ARGS; }
+    }
+    if (n_tracks == 0) return SRK_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    struct { DevBuf* b; const void* src; size_t bytes; } up[] = {
+        { &h->sc_pts, x_meter, (size_t)(24 * O) },       { &h->sc_R, cam_R, (size_t)(72 * (int64_t)n_frames) },
+        { &h->sc_T, cam_T, (size_t)(24 * (int64_t)n_frames) }, { &h->sc_frame, frame, (size_t)(4 * O) },
+        { &h->sc_uv, row_ptr, (size_t)(8 * (n_tracks + 1)) },
+    };
+    for (auto& u : up) {
+        if ((rc = dev_alloc(h, *u.b, u.bytes)) != SRK_OK) return rc;
+        if (u.bytes) HIPCHK(h, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = dev_alloc(h, h->sc_partial, (size_t)(8 * n_tracks))) != SRK_OK) return rc;
+    srk_launch_mvf_depth(s, n_tracks, P<int64_t>(h->sc_uv), P<int32_t>(h->sc_frame), P<double>(h->sc_pts), P<double>(h->sc_R),
+                         P<double>(h->sc_T), P<double>(h->sc_partial));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(depth_out, h->sc_partial.p, (size_t)(8 * n_tracks), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SRK_OK;
+}
+
+extern "C" int srk_mvf_relative_motion(srk_ba* h, int64_t n_points, const double* x_anchor, const double* x_target,
+                                       const double* depth_anchor, double* R_out, double* T_out)
+{
+    if (!h) return SRK_E_ARGS;
+    // every point contributes two independent equations ([x2]x has rank 2) towards the 11 needed for a unique
+    // null vector of the 12 unknowns: fewer than 6 points leave the answer arbitrary (the reference does not check)
+    if (n_points < 6 || !x_anchor || !x_target || !depth_anchor || !R_out || !T_out) {
+        h->last_error = "srk_mvf_relative_motion: need at least 6 common points and non-null arrays";
+        return SRK_E_ARGS;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    const int64_t nblk = (n_points + 255) / 256;
+    struct { DevBuf* b; const void* src; size_t bytes; } up[] = {
+        { &h->sc_pts, x_anchor, (size_t)(24 * n_points) }, { &h->sc_uv, x_target, (size_t)(24 * n_points) },
+        { &h->sc_R, depth_anchor, (size_t)(8 * n_points) },
+    };
+    for (auto& u : up) {
+        if ((rc = dev_alloc(h, *u.b, u.bytes)) != SRK_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = dev_alloc(h, h->sc_partial, (size_t)(8 * 78 * nblk))) != SRK_OK) return rc;
+    srk_launch_mvf_gram(s, n_points, P<double>(h->sc_pts), P<double>(h->sc_uv), P<double>(h->sc_R), P<double>(h->sc_partial));
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> part((size_t)(78 * nblk));
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->sc_partial.p, part.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    double G[144], V[144], ev[12];
+    int e = 0;
+    for (int a = 0; a < 12; ++a)
+        for (int b = a; b < 12; ++b, ++e) {
+            double sum = 0;
+            for (int64_t k = 0; k < nblk; ++k) sum += part[(size_t)(78 * k + e)]; // fixed order
+            G[a * 12 + b] = G[b * 12 + a] = sum;
+        }
+    jacobi_eig(12, G, V, ev);
+    int jmin = 0;
+    for (int j = 1; j < 12; ++j)
+        if (ev[j] < ev[jmin]) jmin = j;
+    double Rn[9], Tn[3];
+    for (int col = 0; col < 3; ++col) // vec(R) is column-major in the reference (:174)
+        for (int row = 0; row < 3; ++row) Rn[3 * row + col] = V[(3 * col + row) * 12 + jmin];
+    for (int i = 0; i < 3; ++i) Tn[i] = V[(9 + i) * 12 + jmin];
+    return project_onto_so3(Rn, Tn, R_out, T_out) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ downloads for the parity tests
 
 int64_t srk_ba_buffer_size(srk_ba* h, int which)

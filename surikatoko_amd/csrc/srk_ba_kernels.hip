@@ -1193,3 +1193,95 @@ void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, cons
     hipLaunchKernelGGL(k_env_pack, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, env_off, S, packed,
                        dir);
 }
+
+// ------------------------------------------------------------------ multi-view-factorization steps
+// Estimate3DPointDepthFromFrames (multi-view-factorization.cpp:223-253, MASKS 8.44), one thread per track: observation
+// 0 of a track is its base frame, frame_from_base = SE3AFromB(frame_i_from_world, base_from_world) (:205-213).
+__global__ __launch_bounds__(256) void k_mvf_depth(int64_t n, const int64_t* __restrict__ row_ptr,
+                                                   const int32_t* __restrict__ frame, const double* __restrict__ x,
+                                                   const double* __restrict__ R, const double* __restrict__ T,
+                                                   double* __restrict__ depth)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o0 = row_ptr[i], o1 = row_ptr[i + 1];
+    if (o1 - o0 < 2) { depth[i] = __builtin_nan(""); return; }
+    const double* Rb = R + 9 * (int64_t)frame[o0];
+    const double* Tb = T + 3 * (int64_t)frame[o0];
+    const double x10 = x[3 * o0], x11 = x[3 * o0 + 1], x12 = x[3 * o0 + 2];
+    double num = 0, den = 0;
+    for (int64_t o = o0 + 1; o < o1; ++o) {
+        const double* Ri = R + 9 * (int64_t)frame[o];
+        const double* Ti = T + 3 * (int64_t)frame[o];
+        double Tr[3], v[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double r0 = Ri[3 * a] * Rb[0] + Ri[3 * a + 1] * Rb[1] + Ri[3 * a + 2] * Rb[2];
+            double r1 = Ri[3 * a] * Rb[3] + Ri[3 * a + 1] * Rb[4] + Ri[3 * a + 2] * Rb[5];
+            double r2 = Ri[3 * a] * Rb[6] + Ri[3 * a + 1] * Rb[7] + Ri[3 * a + 2] * Rb[8];
+            Tr[a] = Ti[a] - (r0 * Tb[0] + r1 * Tb[1] + r2 * Tb[2]);
+            v[a] = r0 * x10 + r1 * x11 + r2 * x12;
+        }
+        const double xi0 = x[3 * o], xi1 = x[3 * o + 1], xi2 = x[3 * o + 2];
+        const double h10 = xi1 * Tr[2] - xi2 * Tr[1], h11 = xi2 * Tr[0] - xi0 * Tr[2], h12 = xi0 * Tr[1] - xi1 * Tr[0];
+        const double h20 = xi1 * v[2] - xi2 * v[1], h21 = xi2 * v[0] - xi0 * v[2], h22 = xi0 * v[1] - xi1 * v[0];
+        num += h10 * h20 + h11 * h21 + h12 * h22;
+        den += h10 * h10 + h11 * h11 + h12 * h12;
+    }
+    depth[i] = 1.0 / (-num / den);
+}
+
+// FindRelativeMotionMultiPoints (:107-189): Gram matrix A^T A (12 x 12, 78 unique sums) of the 3P x 12 system whose
+// rows are [x2]x (kron(x1^T, I) | alpha I); the right singular vector of A's smallest singular value is the
+// eigenvector of the smallest eigenvalue of A^T A (host, 12 x 12).  One block per 256 points, fixed-order sums.
+__global__ __launch_bounds__(256) void k_mvf_gram(int64_t P, const double* __restrict__ xa, const double* __restrict__ xt,
+                                                  const double* __restrict__ depth, double* __restrict__ partial /* [grid][78] */)
+{
+    __shared__ double red[4][78];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double row[3][12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 12; ++c) row[r][c] = 0;
+    if (i < P) {
+        const double c1[3] = { xa[3 * i], xa[3 * i + 1], xa[3 * i + 2] };
+        const double c2[3] = { xt[3 * i], xt[3 * i + 1], xt[3 * i + 2] };
+        const double sk[3][3] = { { 0, -c2[2], c2[1] }, { c2[2], 0, -c2[0] }, { -c2[1], c2[0], 0 } };
+        const double alpha = 1.0 / depth[i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) row[r][3 * comp + cc] = c1[comp] * sk[r][cc];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) row[r][9 + cc] = alpha * sk[r][cc];
+        }
+    }
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < 12; ++a)
+#pragma unroll
+        for (int b = a; b < 12; ++b) {
+            double g = row[0][a] * row[0][b] + row[1][a] * row[1][b] + row[2][a] * row[2][b];
+            g = wave_sum(g);
+            if (lane == 0) red[wave][e] = g;
+            ++e;
+        }
+    __syncthreads();
+    if (threadIdx.x < 78)
+        partial[(int64_t)blockIdx.x * 78 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+void srk_launch_mvf_depth(hipStream_t s, int64_t n, const int64_t* row_ptr, const int32_t* frame, const double* x,
+                          const double* R, const double* T, double* depth)
+{
+    if (n > 0) hipLaunchKernelGGL(k_mvf_depth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, row_ptr, frame, x, R, T, depth);
+}
+void srk_launch_mvf_gram(hipStream_t s, int64_t P, const double* xa, const double* xt, const double* depth, double* partial)
+{
+    if (P > 0) hipLaunchKernelGGL(k_mvf_gram, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, xa, xt, depth, partial);
+}

@@ -82,6 +82,12 @@ void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, doub
 void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
                          double* packed, int dir);
 
+// ---- multi-view-factorization steps (srk_ba_kernels.hip) ----
+void srk_launch_mvf_depth(hipStream_t s, int64_t n_tracks, const int64_t* row_ptr, const int32_t* frame, const double* x_meter,
+                          const double* cam_R, const double* cam_T, double* depth);
+void srk_launch_mvf_gram(hipStream_t s, int64_t n_points, const double* x_anchor, const double* x_target, const double* depth,
+                         double* partial /* [ceil(P / 256)][78] upper triangle of A^T A, row by row */);
+
 // optional profile of one solve: event pairs around every MFMA trailing-update launch (n pairs recorded, at most
 // cap / 2) and the flops those launches execute; dry = count only, launch nothing
 struct SrkSolveProf {
