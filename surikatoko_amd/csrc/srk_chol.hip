@@ -70,54 +70,81 @@ __device__ __forceinline__ double fast_rsqrt(double d)
     return r;
 }
 
-// Branch-free inner loop: entries above the diagonal are updated too (never read), so the only per-element
-// predicate left is "column > pivot column" inside the pivot's own group of four.
-__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sCol /*[2][64]*/, double* sDiag /*[64]*/,
-                                        double* sInv /*[64]*/)
+// Four pivots per barrier pair.  A per-pivot scheme pays one LDS round trip + barrier (~150 cycles) and one reciprocal
+// chain per pivot (~340 cycles in all, 64 times).  Here the columns are taken in groups of four (the four columns a
+// quad owns in one register slot):
+//   A. every thread publishes its entry of the group's 64 x 4 panel; after the barrier all threads read the group's
+//      4 x 4 diagonal block and factor it redundantly in registers (4 dependent reciprocals, no LDS in between);
+//   B. every quad gathers its row of the panel with DPP broadcasts, eliminates it against that 4 x 4 factor (final,
+//      unscaled entries y_i and multipliers l_i = y_i / d), publishes y_i; after the second barrier each thread reads
+//      y_c for its column-rows c and applies the rank-4 update a_ic -= sum_k l_ik y_ck.
+// The slot of the NEXT group is updated and published first, so its barrier round trip hides under the other updates.
+// Entries above the diagonal are updated too (never read): no per-element predicates.
+__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][64][4]: panel P, finals Y*/,
+                                        double* sDiag /*[64]*/, double* sInv /*[64]*/)
 {
     const int t = threadIdx.x, i = t >> 2, q = t & 3;
+    double (*sP)[4] = reinterpret_cast<double (*)[4]>(sPY);
+    double (*sY)[4] = reinterpret_cast<double (*)[4]>(sPY + 4 * NB);
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = sD[i][4 * m + q];
     // pivot health as two running scalars (a per-pivot flag would keep all 64 pivots live until the end):
     // dmin <= 0 catches non-positive pivots, 0 * d turns Inf / NaN into NaN
     double dmin = 1.0, dchk = 0.0;
-    // Software-pipelined pivots: inside step j the entry of the NEXT pivot column is updated and published first,
-    // the barrier follows at once, and the other 15 updates of step j run under the LDS latency of column j + 1.
-    if (q == 0) sCol[i] = a[0];
+    sP[i][q] = a[0];
     __syncthreads();
-    double dj = sCol[0], ci = sCol[i], cc[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) cc[m] = sCol[4 * m + q];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        dmin = fmin(dmin, dj);
-        dchk = fma(0.0, dj, dchk);
-        const double li = ci * fast_rcp(dj);
-        const double lpred = (q > (j & 3)) ? li : 0.0; // inside the pivot's own group of four only columns > j
-        const int m0 = j >> 2, m1 = (j + 1) >> 2;
-        double dn = 0, cin = 0, ccn[16];
-        if (j + 1 < NB) {
-            a[m1] = fma(-(m1 == m0 ? lpred : li), cc[m1], a[m1]);
-            double* coln = sCol + ((j + 1) & 1) * NB;
-            if (q == ((j + 1) & 3)) coln[i] = a[m1];
-            __syncthreads();
-            dn = coln[j + 1];
-            cin = coln[i];
-#pragma unroll
-            for (int m = m1; m < 16; ++m) ccn[m] = coln[4 * m + q];
+    for (int g = 0; g < 16; ++g) {
+        // ---- A: the 4 x 4 diagonal block of the group (rows 4g .. 4g+3 of the panel), LDL^T with unscaled entries
+        const double2* Dp = reinterpret_cast<const double2*>(&sP[4 * g][0]);
+        const double2 d0 = Dp[0], d1 = Dp[2], d2a = Dp[4], d2b = Dp[5], d3a = Dp[6], d3b = Dp[7];
+        const double u00 = d0.x;
+        const double r0 = fast_rcp(u00);
+        const double u10 = d1.x, u20 = d2a.x, u30 = d3a.x;
+        const double l10 = u10 * r0, l20 = u20 * r0, l30 = u30 * r0;
+        const double u11 = fma(-l10, u10, d1.y);
+        const double r1 = fast_rcp(u11);
+        const double u21 = fma(-l20, u10, d2a.y), u31 = fma(-l30, u10, d3a.y);
+        const double l21 = u21 * r1, l31 = u31 * r1;
+        const double u22 = fma(-l21, u21, fma(-l20, u20, d2b.x));
+        const double r2 = fast_rcp(u22);
+        const double u32 = fma(-l31, u21, fma(-l30, u20, d3b.x));
+        const double l32 = u32 * r2;
+        const double u33 = fma(-l32, u32, fma(-l31, u31, fma(-l30, u30, d3b.y)));
+        const double r3 = fast_rcp(u33);
+        dmin = fmin(fmin(dmin, u00), fmin(u11, fmin(u22, u33)));
+        dchk = fma(0.0, u00, fma(0.0, u11, fma(0.0, u22, fma(0.0, u33, dchk))));
+        // ---- B: this row against the factor.  y_k = p_k - sum_{k' < k} (y_k' / d_k') u_kk'
+        const double p0 = quad_bcast<0>(a[g]), p1 = quad_bcast<1>(a[g]), p2 = quad_bcast<2>(a[g]), p3 = quad_bcast<3>(a[g]);
+        const double y0 = p0, z0 = y0 * r0;
+        const double y1 = fma(-z0, u10, p1), z1 = y1 * r1;
+        const double y2 = fma(-z1, u21, fma(-z0, u20, p2)), z2 = y2 * r2;
+        const double y3 = fma(-z2, u32, fma(-z1, u31, fma(-z0, u30, p3))), z3 = y3 * r3;
+        {
+            const double y01 = (q & 1) ? y1 : y0, y23 = (q & 1) ? y3 : y2;
+            a[g] = (q & 2) ? y23 : y01; // final (unscaled) entry of column 4g + q
+        }
+        if (g == 15) break;
+        sY[i][q] = a[g];
+        __syncthreads();
+        // the next group's slot first: update, publish, barrier -- the remaining slots follow under that latency
+        {
+            const double2* yp = reinterpret_cast<const double2*>(&sY[4 * (g + 1) + q][0]);
+            const double2 y01 = yp[0], y23 = yp[1];
+            a[g + 1] = fma(-z3, y23.y, fma(-z2, y23.x, fma(-z1, y01.y, fma(-z0, y01.x, a[g + 1]))));
+            sP[i][q] = a[g + 1];
         }
 #pragma unroll
-        for (int m = m0; m < 16; ++m) {
-            if (m == m1 && j + 1 < NB) continue; // already done above
-            a[m] = fma(-(m == m0 ? lpred : li), cc[m], a[m]);
+        for (int m = g + 2; m < 16; ++m) {
+            const double2* yp = reinterpret_cast<const double2*>(&sY[4 * m + q][0]);
+            const double2 y01 = yp[0], y23 = yp[1];
+            a[m] = fma(-z3, y23.y, fma(-z2, y23.x, fma(-z1, y01.y, fma(-z0, y01.x, a[m]))));
+            if (((m - g) & 3) == 1) asm volatile("" ::: "memory"); // keep <= 8 sixteen-byte reads in flight
         }
-        dj = dn;
-        ci = cin;
-#pragma unroll
-        for (int m = m1; m < 16; ++m) cc[m] = ccn[m];
+        __syncthreads(); // panel of group g + 1 is complete (and every read of sY is done)
     }
-    // the owner of a diagonal entry still holds its pivot d_i (entries are final once their column is passed)
+    // the owner of a diagonal entry holds its pivot d_i
 #pragma unroll
     for (int m = 0; m < 16; ++m)
         if (4 * m + q == i) sDiag[i] = a[m];
@@ -178,7 +205,7 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
         if ((int64_t)blockIdx.x >= blocks) return; // the grid is sized for the largest item of the batch
     }
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
-    __shared__ double sCol[2 * NB];
+    __shared__ __attribute__((aligned(16))) double sCol[8 * NB]; // potrf64: panel [64][4] + finals [64][4]
     __shared__ double sDiag[NB];
     __shared__ double sInv[NB];
     __shared__ double sy[NB];

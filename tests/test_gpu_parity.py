@@ -367,6 +367,35 @@ def test_c2_size_properties(gpu):
     assert e_final == pytest.approx(errs[-1], rel=1e-6)
 
 
+def test_c3_solver_modes_agree_at_bench_size(gpu):
+    """The bench workload (BASELINE config 3: 1000 cams / 100k pts / 2M obs): one LM iteration through the nested
+    dissection (4 levels), the single skyline chain and the dense factorisation must be the same step -- same error,
+    same corrections; and a second iteration still decreases the error."""
+    spec = sa.CONFIGS["C3_1kcam_100kpt"]
+    sc = sa.generate_scene(spec)
+    res = {}
+    try:
+        for mode in (2, 1, 0):
+            gpu.set_rcs_mode(mode)
+            assert gpu.upload(spec.f0, sc)
+            if mode == 2:
+                assert gpu.rcs_chunks() >= 8 and gpu.rcs_fill() < 0.15
+            ok = gpu.optimize(None, max_iterations=1)
+            assert not ok and gpu.report.iterations == 1 and gpu.report.attempts == 1
+            res[mode] = (gpu.report.err_initial, gpu.report.err_final, gpu.buffer(B.BUF_CORRECTIONS).copy())
+    finally:
+        gpu.set_rcs_mode(2)
+    e0, e1, corr = res[1]
+    assert e1 < e0
+    for mode in (2, 0):
+        assert res[mode][0] == e0
+        assert res[mode][1] == pytest.approx(e1, rel=1e-9)
+        assert rel_err(res[mode][2], corr) < 1e-8
+    assert gpu.upload(spec.f0, sc)
+    gpu.optimize(None, max_iterations=2)
+    assert gpu.report.iterations == 2 and gpu.report.err_final < e1
+
+
 # ------------------------------------------------------------------ sharded path, world size 1 on the GPU
 
 def test_allreduce_hook_with_device_pointers(orc, gpu):

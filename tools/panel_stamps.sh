@@ -4,12 +4,12 @@ set -e
 cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
 cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DSRK_PANEL_STAMPS -c srk_chol.hip -o /tmp/chol_st.o 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so srk_ba_kernels.o /tmp/chol_st.o srk_ba_host.o srk_scene.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so srk_ba_kernels.o /tmp/chol_st.o srk_ba_host.o srk_scene.o srk_io.o
 (cd "$GRAFT_REPO_ROOT" && python - <<'PY'
 import ctypes as C, numpy as np
 import surikatoko_amd as sa
 spec=sa.CONFIGS["C3_1kcam_100kpt"]; sc=sa.generate_scene(spec)
-ba=sa.BundleAdjustmentKanatani(0); ba.upload(spec.f0, sc)
+ba=sa.BundleAdjustmentKanatani(0); ba.set_rcs_mode(1); ba.upload(spec.f0, sc)
 for _ in range(2):
     ba.reset(); ba.optimize(None, max_iterations=1)
 out=(C.c_longlong*16)()
