@@ -113,6 +113,17 @@ int srk_ba_compute_inplace(srk_ba*, double f0,
                            int64_t max_iterations /* <= 0 = unlimited (reference behaviour) */,
                            srk_ba_report* out);
 
+/* The same call for a reference built with Scalar = float (rt-config.h:41-48; CMake option suriko_scalar_type_string =
+ * f32, suriko-engine/CMakeLists.txt:14-15,76-82): float arrays at the boundary, widened to the fp64 pipeline and
+ * rounded back (strictly more accurate than the reference's f32 arithmetic; there is no f32 device pipeline). */
+int srk_ba_compute_inplace_f32(srk_ba*, float f0,
+                               int64_t n_points, float* points_xyz,
+                               int32_t n_frames, float* cam_R, float* cam_T,
+                               const float* K, int shared_k,
+                               const int64_t* obs_row_ptr, const int32_t* obs_frame, const float* obs_uv,
+                               const float* allowed_err_change, const float* max_hessian_factor,
+                               int64_t max_iterations, srk_ba_report* out);
+
 double srk_ba_reproj_error(srk_ba*, double f0,
                            int64_t n_points, const double* points_xyz,
                            int32_t n_frames, const double* cam_R, const double* cam_T,

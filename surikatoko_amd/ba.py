@@ -181,6 +181,29 @@ class BundleAdjustmentKanatani:
         self._status = status_string(self.report.status)
         return rc == 0
 
+    def ComputeInplaceF32(self, f0, points, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv, term_crit=None,
+                          max_iterations=0):
+        """The call of a reference built with Scalar = float: float32 arrays (updated in place) at the boundary, the
+        fp64 pipeline inside (srk_ba_compute_inplace_f32)."""
+        for arr in (points, cam_R, cam_T, K, obs_uv):
+            if arr.dtype != np.float32 or not arr.flags["C_CONTIGUOUS"]:
+                raise ValueError("ComputeInplaceF32 takes C-contiguous float32 arrays")
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        fr = np.ascontiguousarray(obs_frame, dtype=np.int32)
+        a64, m64 = self._criteria(term_crit)
+        a32 = C.c_float(term_crit.AllowedReprojErrRelativeChange()) if a64 is not None else None
+        m32 = C.c_float(term_crit.MaxHessianFactor()) if m64 is not None else None
+        self._f0 = float(f0)
+        self.report = Report()
+        rc = self._lib.srk_ba_compute_inplace_f32(
+            C.c_void_p(self._h), C.c_float(f0), C.c_int64(points.shape[0]), _p(points), C.c_int32(cam_R.shape[0]), _p(cam_R),
+            _p(cam_T), _p(K), C.c_int(int(bool(shared_k))), _p(rp), _p(fr), _p(obs_uv),
+            C.byref(a32) if a32 is not None else None, C.byref(m32) if m32 is not None else None,
+            C.c_int64(max_iterations), C.byref(self.report))
+        self._raise(rc)
+        self._status = status_string(self.report.status)
+        return rc == 0
+
     def ReprojError(self, f0, scene):
         """static Scalar ReprojError(...) (.h:167-172, .cpp:410-490) -> (err, seen_points_count)."""
         seen = C.c_int64(0)

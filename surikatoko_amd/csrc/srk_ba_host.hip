@@ -1243,6 +1243,36 @@ int srk_ba_reproj_error_mvf(srk_ba* h, double f0, int64_t N, const double* pts, 
     return 1;
 }
 
+// ------------------------------------------------------------------ f32 boundary (suriko_scalar_type_string = f32)
+// A reference built with Scalar = float (rt-config.h:41-48, suriko-engine/CMakeLists.txt:14-15,76-82) hands over float
+// arrays.  They are widened here, the fp64 pipeline runs unchanged, the result is rounded back: the arithmetic is
+// strictly more accurate than the reference's own f32 build (an f32 device pipeline is not implemented).
+extern "C" int srk_ba_compute_inplace_f32(srk_ba* h, float f0, int64_t N, float* pts, int32_t M, float* cam_R, float* cam_T,
+                                          const float* K, int shared_k, const int64_t* row_ptr, const int32_t* obs_frame,
+                                          const float* obs_uv, const float* allowed_err_change,
+                                          const float* max_hessian_factor, int64_t max_iterations, srk_ba_report* out)
+{
+    if (!h) return SRK_E_ARGS;
+    if (N < 0 || M < 1 || !row_ptr || !cam_R || !cam_T || !K || (N > 0 && !pts)) {
+        h->last_error = "null scene array";
+        return SRK_E_ARGS;
+    }
+    const int64_t O = row_ptr[N];
+    if (O > 0 && !obs_uv) { h->last_error = "null observation arrays"; return SRK_E_ARGS; }
+    auto widen = [](const float* p, size_t n) { return std::vector<double>(p, p + n); };
+    std::vector<double> dp = widen(pts, (size_t)(3 * N)), dR = widen(cam_R, 9 * (size_t)M), dT = widen(cam_T, 3 * (size_t)M),
+                        dK = widen(K, shared_k ? 9 : 9 * (size_t)M), duv = widen(obs_uv, (size_t)(2 * O));
+    double a = allowed_err_change ? (double)*allowed_err_change : 0, m = max_hessian_factor ? (double)*max_hessian_factor : 0;
+    int rc = srk_ba_compute_inplace(h, (double)f0, N, dp.data(), M, dR.data(), dT.data(), dK.data(), shared_k, row_ptr,
+                                    obs_frame, duv.data(), allowed_err_change ? &a : nullptr,
+                                    max_hessian_factor ? &m : nullptr, max_iterations, out);
+    if (rc < 0) return rc;
+    for (size_t i = 0; i < dp.size(); ++i) pts[i] = (float)dp[i];
+    for (size_t i = 0; i < dR.size(); ++i) cam_R[i] = (float)dR[i];
+    for (size_t i = 0; i < dT.size(); ++i) cam_T[i] = (float)dT[i];
+    return rc;
+}
+
 // ------------------------------------------------------------------ multi-view-factorization steps
 namespace {
 // cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major, destroyed): V's columns = eigenvectors

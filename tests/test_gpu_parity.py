@@ -582,3 +582,29 @@ def test_mvf_scorer_matches_oracle_and_skips_points_at_infinity(orc, gpu):
     assert not ok3 and n3 == 0
     with pytest.raises(ValueError):
         gpu.ReprojErrorMvf(0.0, sc)
+
+
+# ------------------------------------------------------------------ f32 boundary (reference built with Scalar = float)
+
+def test_f32_boundary_matches_f64_run_on_the_same_rounded_inputs(gpu):
+    """srk_ba_compute_inplace_f32 = widen -> fp64 pipeline -> round: its result must be the float rounding of the f64
+    call on the float-rounded inputs, with the same accept / reject sequence."""
+    spec = SCENES["pixel_noise"]
+    sc = sa.generate_scene(spec)
+    f32 = {k: np.ascontiguousarray(getattr(sc, k), dtype=np.float32) for k in ("points", "cam_R", "cam_T", "K", "obs_uv")}
+    sc64 = sa.Scene(f32["points"].astype(np.float64), f32["cam_R"].astype(np.float64), f32["cam_T"].astype(np.float64),
+                    f32["K"].astype(np.float64), sc.shared_k, sc.row_ptr, sc.obs_frame, f32["obs_uv"].astype(np.float64))
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(float(np.float32(1e-6)))
+    ok64 = gpu.ComputeInplace(float(np.float32(spec.f0)), sc64, crit, 6)
+    rep64 = (gpu.report.iterations, gpu.report.attempts, gpu.report.status)
+    ok32 = gpu.ComputeInplaceF32(spec.f0, f32["points"], f32["cam_R"], f32["cam_T"], f32["K"], sc.shared_k, sc.row_ptr,
+                                 sc.obs_frame, f32["obs_uv"], crit, 6)
+    assert ok32 == ok64 and (gpu.report.iterations, gpu.report.attempts, gpu.report.status) == rep64
+    for k in ("points", "cam_R", "cam_T"):
+        want = getattr(sc64, k).astype(np.float32).reshape(f32[k].shape)
+        # fp64 atomics reorder sums run to run: allow one float ulp
+        assert np.abs(f32[k] - want).max() <= 2 * np.finfo(np.float32).eps * max(1.0, float(np.abs(want).max()))
+    with pytest.raises(ValueError):
+        gpu.ComputeInplaceF32(spec.f0, sc.points, f32["cam_R"], f32["cam_T"], f32["K"], sc.shared_k, sc.row_ptr,
+                              sc.obs_frame, f32["obs_uv"])
