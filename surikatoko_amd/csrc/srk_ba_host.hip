@@ -57,8 +57,8 @@ struct srk_ba {
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
     std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
-    DevBuf env_col, env_off, packed, dinv;
-    int64_t env_packed = 0;
+    DevBuf env_col, env_off, packed, dinv, band_col, band_off;
+    int64_t env_packed = 0, band_packed = 0; // doubles inside the factorisation skyline / the pre-factorisation band
     bool use_envelope = true;
     // chunked solve of a banded system (srk_chol.hip): plan + its buffers
     bool use_chunks = true;
@@ -71,6 +71,7 @@ struct srk_ba {
     srk_allreduce_fn allreduce = nullptr;
     void* allreduce_ctx = nullptr;
     int rank = 0, world = 1;
+    int64_t seen_global = -1; // observation count over all ranks of the uploaded scene (-1 = not yet exchanged)
 
     // timing
     hipEvent_t ev[16]{};
@@ -161,7 +162,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
                       &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
                       &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
-                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv };
+                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv, &h->band_col, &h->band_off };
     for (DevBuf* b : all) dev_free(*b);
     for (DevBuf& b : h->plan_bufs) dev_free(b);
     for (DevBuf* b : { &h->sc_pts, &h->sc_R, &h->sc_T, &h->sc_K, &h->sc_cam, &h->sc_frame, &h->sc_pt, &h->sc_uv, &h->sc_partial, &h->sc_out })
@@ -207,6 +208,7 @@ int srk_ba_set_allreduce(srk_ba* h, srk_allreduce_fn fn, void* ctx, int rank, in
     h->allreduce_ctx = ctx;
     h->rank = rank;
     h->world = world_size;
+    h->seen_global = -1;
     return SRK_OK;
 }
 
@@ -483,6 +485,22 @@ static int build_envelope(srk_ba* h)
     if ((rc = dev_alloc(h, h->env_off, (size_t)(8 * (nt + 1)))) != SRK_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(h->env_col.p, h->env_col_h.data(), (size_t)(8 * nt), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->env_off.p, h->env_off_h.data(), (size_t)(8 * (nt + 1)), hipMemcpyHostToDevice, h->stream));
+    // exchange format of the assembled system (landmark shards): the exact pre-factorisation band of every row
+    {
+        std::vector<int64_t> bc((size_t)d.ld), bo((size_t)d.ld + 1, 0);
+        for (int64_t r = 0; r < d.ld; ++r) {
+            int64_t c0 = r; // padding rows: the diagonal only
+            if (r < 10 * (int64_t)d.M) c0 = h->use_envelope ? 10 * (int64_t)h->min_cv[(size_t)(r / 10)] : 0;
+            bc[(size_t)r] = c0;
+            bo[(size_t)r + 1] = bo[(size_t)r] + (r - c0 + 1);
+        }
+        h->band_packed = bo[(size_t)d.ld];
+        if ((rc = dev_alloc(h, h->band_col, (size_t)(8 * d.ld))) != SRK_OK) return rc;
+        if ((rc = dev_alloc(h, h->band_off, (size_t)(8 * (d.ld + 1)))) != SRK_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->band_col.p, bc.data(), (size_t)(8 * d.ld), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->band_off.p, bo.data(), (size_t)(8 * (d.ld + 1)), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream)); // bc / bo are locals
+    }
     HIPCHK(h, hipMemsetAsync(h->S.p, 0, (size_t)(8 * d.ld * d.ld), h->stream)); // everything outside the skyline stays 0
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return build_chunk_plan(h);
@@ -497,6 +515,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     if (rc != SRK_OK) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     h->have_scene = false;
+    h->seen_global = -1;
     int64_t O = row_ptr[N];
     std::vector<double> pts(pts_in, pts_in + 3 * N), camR(cam_R_in, cam_R_in + 9 * (int64_t)M),
         camT(cam_T_in, cam_T_in + 3 * (int64_t)M);
@@ -860,15 +879,15 @@ static int phase_schur(srk_ba* h, double c)
     // before the exchange; the identity diagonal of fixed / padding variables comes from rank 0 alone
     srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->S), P<double>(h->rhs), h->rank == 0 ? 1.0 : 0.0);
     HIPCHK(h, hipGetLastError());
-    if (h->allreduce) { // landmark shards: ONE exchange per attempt; only the skyline travels, the rhs rides behind it
+    if (h->allreduce) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
         int rc;
-        if ((rc = dev_alloc(h, h->packed, (size_t)(8 * (h->env_packed + d.ld)))) != SRK_OK) return rc;
-        double* tail = P<double>(h->packed) + h->env_packed;
-        srk_launch_env_pack(s, d.ld, P<int64_t>(h->env_col), P<int64_t>(h->env_off), P<double>(h->S), P<double>(h->packed), 0);
+        if ((rc = dev_alloc(h, h->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
+        double* tail = P<double>(h->packed) + h->band_packed;
+        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->S), P<double>(h->packed), 0);
         HIPCHK(h, hipMemcpyAsync(tail, h->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
-        rc = exchange(h, P<double>(h->packed), h->env_packed + d.ld);
+        rc = exchange(h, P<double>(h->packed), h->band_packed + d.ld);
         if (rc != SRK_OK) return rc;
-        srk_launch_env_pack(s, d.ld, P<int64_t>(h->env_col), P<int64_t>(h->env_off), P<double>(h->S), P<double>(h->packed), 1);
+        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->S), P<double>(h->packed), 1);
         HIPCHK(h, hipMemcpyAsync(h->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipGetLastError());
     }
@@ -1023,14 +1042,19 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
 
     double hessian_factor = (double)0.0001f; // :723 (float literal)
     // seen_points_count over all shards (:483, :726)
-    double seen_d = (double)d.O;
-    if (h->allreduce) {
-        HIPCHK(h, hipMemcpyAsync(h->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
-        int rc = exchange(h, P<double>(h->err_out), 1);
-        if (rc != SRK_OK) return fail_device(rc);
-        HIPCHK(h, hipMemcpyAsync(&seen_d, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
+    // once per uploaded scene: it does not change between optimise calls
+    if (h->seen_global < 0) {
+        double seen_d = (double)d.O;
+        if (h->allreduce) {
+            HIPCHK(h, hipMemcpyAsync(h->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
+            int rc = exchange(h, P<double>(h->err_out), 1);
+            if (rc != SRK_OK) return fail_device(rc);
+            HIPCHK(h, hipMemcpyAsync(&seen_d, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+        }
+        h->seen_global = (int64_t)seen_d;
     }
+    const double seen_d = (double)h->seen_global;
     rep->seen = (int64_t)seen_d;
 
     double err_initial = 0;

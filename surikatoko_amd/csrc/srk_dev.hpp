@@ -81,6 +81,8 @@ void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
 void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S);
 void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
                          double* packed, int dir);
+void srk_launch_band_pack(hipStream_t s, int64_t ld, const int64_t* band_col, const int64_t* band_off, double* S,
+                          double* packed, int dir /* 0 pack, 1 unpack */);
 
 // ---- multi-view-factorization steps (srk_ba_kernels.hip) ----
 void srk_launch_mvf_depth(hipStream_t s, int64_t n_tracks, const int64_t* row_ptr, const int32_t* frame, const double* x_meter,

@@ -36,6 +36,17 @@ def make_allreduce_hook(group=None, device=None, chunk_elems=1 << 27):
     import torch
     import torch.distributed as dist
 
+    views = {}  # (pointer, count) -> tensor view: the library exchanges the same few buffers every attempt
+
+    def _view(ptr, n):
+        key = (int(ptr), int(n))
+        t = views.get(key)
+        if t is None:
+            if len(views) > 64:
+                views.clear()
+            t = views[key] = tensor_from_pointer(ptr, n, device)
+        return t
+
     def _hook(_ctx, ptr, count):
         try:
             # a CPU-only backend (gloo) with device pointers: stage through host memory (used to rehearse the
@@ -44,7 +55,7 @@ def make_allreduce_hook(group=None, device=None, chunk_elems=1 << 27):
             done = 0
             while done < count:
                 n = min(int(chunk_elems), int(count) - done)
-                t = tensor_from_pointer(int(ptr) + 8 * done, n, device)
+                t = _view(int(ptr) + 8 * done, n)
                 if stage:
                     th = t.cpu()
                     dist.all_reduce(th, op=dist.ReduceOp.SUM, group=group)
