@@ -28,6 +28,10 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it waits
+// for every outstanding global load / store of the wave.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------- 64x64 diagonal tile, register-resident
 // thread t owns row i = t>>2, columns c = 4m + (t&3), m = 0..15.  Outer-product Cholesky with deferred scaling:
 // at step j the pivot d_j = a_jj is final and a_ic -= a_ij a_cj / d_j for c > j; column j is published through a
@@ -93,7 +97,7 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
     // dmin <= 0 catches non-positive pivots, 0 * d turns Inf / NaN into NaN
     double dmin = 1.0, dchk = 0.0;
     sP[i][q] = a[0];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         // ---- A: the 4 x 4 diagonal block of the group (rows 4g .. 4g+3 of the panel), LDL^T with unscaled entries
@@ -127,7 +131,7 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
         }
         if (g == 15) break;
         sY[i][q] = a[g];
-        __syncthreads();
+        lds_barrier();
         // the next group's slot first: update, publish, barrier -- the remaining slots follow under that latency
         {
             const double2* yp = reinterpret_cast<const double2*>(&sY[4 * (g + 1) + q][0]);
@@ -142,15 +146,15 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
             a[m] = fma(-z3, y23.y, fma(-z2, y23.x, fma(-z1, y01.y, fma(-z0, y01.x, a[m]))));
             if (((m - g) & 3) == 1) asm volatile("" ::: "memory"); // keep <= 8 sixteen-byte reads in flight
         }
-        __syncthreads(); // panel of group g + 1 is complete (and every read of sY is done)
+        lds_barrier(); // panel of group g + 1 is complete (and every read of sY is done)
     }
     // the owner of a diagonal entry holds its pivot d_i
 #pragma unroll
     for (int m = 0; m < 16; ++m)
         if (4 * m + q == i) sDiag[i] = a[m];
-    __syncthreads();
+    lds_barrier();
     if (t < NB) sInv[t] = fast_rsqrt(sDiag[t]); // 1 / L_tt
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         int c = 4 * m + q;
@@ -158,7 +162,7 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
         v = (c <= i) ? v : 0.0;
         sD[i][c] = v;
     }
-    __syncthreads();
+    lds_barrier();
     return !(dmin > 0.0) || (dchk != 0.0);
 }
 
@@ -184,7 +188,7 @@ struct CholHostItem { const int64_t* row_end; const int64_t* col_begin; }; // ho
 // rows below (so the forward substitution L y = b costs no extra launches).
 #ifdef SRK_PANEL_STAMPS
 __device__ long long g_panel_stamps[16];
-#define STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d == 40) g_panel_stamps[k] = clock64(); } while (0)
+#define STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d == 40) g_panel_stamps[k] = wall_clock64(); } while (0)
 #else
 #define STAMP(k)
 #endif

@@ -16,7 +16,7 @@ out=(C.c_longlong*16)()
 sa.lib().srk_dbg_panel_stamps(out)
 t=[out[i] for i in range(7)]
 names=["load diag","potrf64","store+fwd","row load","row sweep","row store"]
-print("clock64 ticks (100 MHz => x10 ns):")
+print("wall_clock64 ticks (100 MHz => x10 ns); note: the stamps themselves perturb the unrolled sweep")
 for n,a,b in zip(names,t[:-1],t[1:]): print(f"  {n:12s} {b-a:8d} ticks = {(b-a)*10/1000:.2f} us")
 print("  sweep quarters:", out[7]-out[4], out[8]-out[7], out[9]-out[8], out[5]-out[9])
 print("  total", (t[-1]-t[0])*10/1000, "us")
