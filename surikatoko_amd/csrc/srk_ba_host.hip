@@ -706,7 +706,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->dc, 8 * d.ld);
     ALLOC(h->acc, 8 * 3 * d.Ns + 64);
     ALLOC(h->dx, 24 * N);
-    ALLOC(h->err_partial, 8 * 1024);
+    ALLOC(h->err_partial, 8 * std::max<int64_t>(1024, srk_error_partials_staged(d)));
     ALLOC(h->err_out, 64);
     ALLOC(h->info, 64);
     ALLOC(h->grp_first, 4 * grp_first.size());
@@ -823,7 +823,8 @@ static int phase_error(srk_ba* h, int which, double* err_host, bool with_status 
     hipStream_t s = h->stream;
     int32_t np = srk_error_partials(d);
     srk_launch_error(s, d, P<double>(h->pts[which]), P<double>(h->cam[which]), P<int32_t>(h->obs_frame),
-                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->err_partial), np, P<double>(h->err_out));
+                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->err_partial), np, P<double>(h->err_out),
+                     h->jac_fused ? P<int32_t>(h->wg_jmin) : nullptr);
     if (with_status)
         srk_launch_status_pack(s, P<int>(h->info), reinterpret_cast<const int*>(reinterpret_cast<char*>(h->acc.p) + 8 * 3 * d.Ns),
                                P<double>(h->err_out));
@@ -1116,6 +1117,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             HIPCHK(h, hipStreamSynchronize(s));
             struct { double err; int info; } back{ h->host_back[0], (int)h->host_back[1] };
             const int info2 = (int)h->host_back[2];
+            if (getenv("SRK_DEBUG"))
+                fprintf(stderr, "srk_ba[rank %d] iteration %lld attempt %lld: hessian_factor %.3g err %.17g -> %.17g, solver info %d, "
+                                "point-update info %d\n", h->rank, (long long)rep->iterations + 1, (long long)rep->attempts,
+                        hessian_factor, err_value, back.err, back.info, info2);
             if (!jac_timed) {
                 rep->ms_jacobian += ev_ms(0, 1);
                 rep->ms_jacobian_kernel += ev_ms(12, 13);

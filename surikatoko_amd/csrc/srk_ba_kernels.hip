@@ -1063,6 +1063,53 @@ __global__ __launch_bounds__(256) void k_error(SrkDims d, const double* __restri
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Staged variant: when the host found that every run of SRK_JF_OBS consecutive observations touches at most
+// SRK_JF_SLOTS consecutive frames (the fused Jacobian's condition; wg_jmin = first frame of each run), the 22 camera
+// values an observation needs come from LDS instead of 22 gathers through L1 -- the gathers, not HBM, bound k_error.
+// Same arithmetic, same per-observation order inside a thread; the partial sums are per run.
+__global__ __launch_bounds__(256) void k_error_staged(SrkDims d, const double* __restrict__ pts,
+                                                      const double* __restrict__ cam, const int32_t* __restrict__ obs_frame,
+                                                      const int32_t* __restrict__ obs_pt, const double* __restrict__ obs_uv,
+                                                      const int32_t* __restrict__ wg_jmin, double* __restrict__ partial)
+{
+    __shared__ double sCam[SRK_JF_SLOTS][23]; // R, T, K (0..20), f0; odd stride: conflict-free across frames
+    __shared__ double red[4];
+    const int jmin = wg_jmin[blockIdx.x];
+    {
+        const int nfr = d.M - jmin < SRK_JF_SLOTS ? d.M - jmin : SRK_JF_SLOTS;
+        for (int t = threadIdx.x; t < nfr * 22; t += 256) {
+            const int js = t / 22, e = t - js * 22;
+            sCam[js][e] = cam[(int64_t)SRK_CAM_PACK * (jmin + js) + (e < 21 ? e : 47)];
+        }
+    }
+    __syncthreads();
+    const int64_t o_first = (int64_t)blockIdx.x * SRK_JF_OBS;
+    double sum = 0;
+#pragma unroll
+    for (int ch = 0; ch < SRK_JF_CHUNKS; ++ch) {
+        const int64_t o = o_first + ch * 256 + threadIdx.x;
+        if (o >= d.O) break;
+        const double* c = sCam[obs_frame[o] - jmin];
+        double2 uv = reinterpret_cast<const double2*>(obs_uv)[o];
+        const double* X = pts + 3 * (int64_t)obs_pt[o];
+        double X0 = X[0], X1 = X[1], X2 = X[2];
+        double xc0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+        double xc1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+        double xc2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+        double p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
+        double q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
+        double r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
+        double f0 = c[21];
+        double ex = p / r - uv.x / f0, ey = q / r - uv.y / f0;
+        sum += ex * ex + ey * ey;
+    }
+    sum = wave_sum(sum);
+    int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // scoring variant (MultiViewIterativeFactorizer::ReprojError, multi-view-factorization.cpp:415-475): observations whose
 // homogeneous image point has |z| <= z_tol are skipped (:455-457) and the summands are counted; z_tol < 0 keeps all.
 // partial[0 .. grid) = error sums, partial[grid .. 2 grid) = counts.
@@ -1135,11 +1182,19 @@ int32_t srk_error_partials(const SrkDims& d)
     if (blocks < 1) blocks = 1;
     return (int32_t)(blocks < SRK_ERR_BLOCKS ? blocks : SRK_ERR_BLOCKS);
 }
+int64_t srk_error_partials_staged(const SrkDims& d) { return d.O > 0 ? (d.O + SRK_JF_OBS - 1) / SRK_JF_OBS : 1; }
 
 void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                       const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
-                      int32_t n_partial, double* err_out)
+                      int32_t n_partial, double* err_out, const int32_t* wg_jmin)
 {
+    if (wg_jmin && d.O > 0) { // staged cameras: one partial sum per run of SRK_JF_OBS observations
+        const int64_t nb = srk_error_partials_staged(d);
+        hipLaunchKernelGGL(k_error_staged, dim3((unsigned)nb), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv, wg_jmin,
+                           partial);
+        hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, (int32_t)nb, partial, err_out);
+        return;
+    }
     hipLaunchKernelGGL(k_error, dim3((unsigned)n_partial), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
                        partial);
     hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, err_out);

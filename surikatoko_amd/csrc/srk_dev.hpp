@@ -69,8 +69,10 @@ void srk_launch_cam_apply(hipStream_t s, int32_t M, const double* R, const doubl
                           double* Tn);
 void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                       const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
-                      int32_t n_partial, double* err_out);
+                      int32_t n_partial, double* err_out,
+                      const int32_t* wg_jmin /* fused-Jacobian frame windows, or NULL: gather the cameras */);
 int32_t srk_error_partials(const SrkDims& d);
+int64_t srk_error_partials_staged(const SrkDims& d); // partial sums written when wg_jmin is given
 void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const double* cam, const int32_t* obs_frame,
                             const int32_t* obs_pt, const double* obs_uv, double z_tol /* < 0: keep every observation */,
                             double* partial /* 2 n_partial */, int32_t n_partial, double* out2 /* {error, count} */);

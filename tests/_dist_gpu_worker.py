@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 
 def run(rank, world, port, out_dir, spec_kwargs, iters):
+    os.environ["SRK_DEBUG"] = "1"  # per-attempt trace on stderr: shows up in the pytest log when an assertion fails
     import torch.distributed as dist
     import surikatoko_amd as sa
     from surikatoko_amd.ba import covisibility, revert_normalization
