@@ -237,12 +237,16 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     STAMP(2);
     if (bad && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(info, 1);
     if (blockIdx.x == 0) {
+        // L_dd goes to this tile's slot of the Dinv buffer (k_dinv inverts it there), NOT back into A: the other
+        // workgroups of this launch read the unfactored tile from A when they start, and nothing orders their start
+        // before this store -- a grid larger than the chip, or a GPU shared with other processes, starts some of them
+        // after workgroup 0 is done.  No later kernel reads a diagonal tile of A.
         const int i = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
-        double2* dst = reinterpret_cast<double2*>(Ab + (int64_t)i * ld + cb);
+        double2* dst = reinterpret_cast<double2*>(B.it[blockIdx.z].dinv + d * NB * NB + (int64_t)i * NB + cb);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             int c = cb + 2 * t;
-            if (c <= i) dst[t] = make_double2(sD[i][c], sD[i][c + 1]); // the entry above the diagonal is 0, never read
+            dst[t] = make_double2(sD[i][c], sD[i][c + 1]); // zeros above the diagonal
         }
     }
     STAMP(3);
@@ -588,14 +592,15 @@ __global__ __launch_bounds__(256) void k_dinv(const CholBatch B)
     __shared__ double sT[32][33];
     const int64_t k0 = (int64_t)blockIdx.x * NB;
     if (k0 >= B.it[blockIdx.z].ncols) return;
-    const double* __restrict__ A = B.it[blockIdx.z].A;
     double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
-    const int64_t ld = B.it[blockIdx.z].ld;
     const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += 256) {
-        int i = e >> 6, c = e & 63;
-        sL[i][c] = (c <= i) ? A[(k0 + i) * ld + k0 + c] : 0.0;
-        sZ[i][c] = 0.0;
+    {
+        const double* Ld = Dinv + (int64_t)blockIdx.x * NB * NB; // k_panel left L_dd in this tile's slot
+        for (int e = t; e < NB * NB; e += 256) {
+            int i = e >> 6, c = e & 63;
+            sL[i][c] = (c <= i) ? Ld[e] : 0.0;
+            sZ[i][c] = 0.0;
+        }
     }
     __syncthreads();
     if (t < 64) { // thread (b, c): column c of the inverse of diagonal block b, right-looking in registers

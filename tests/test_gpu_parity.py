@@ -396,6 +396,31 @@ def test_c3_solver_modes_agree_at_bench_size(gpu):
     assert gpu.report.iterations == 2 and gpu.report.err_final < e1
 
 
+def test_c5_nested_dissection_agrees_with_single_chain(gpu):
+    """BASELINE config 5 (4000 cams / 1M pts / 20M obs): two LM iterations through the nested dissection (32 chunks; its
+    batched panel launches carry more workgroups than the chip holds at once, so workgroups of one launch do not all
+    start together) and through the single skyline chain must agree."""
+    spec = sa.CONFIGS["C5_4kcam_1Mpt"]
+    sc = sa.generate_scene(spec)
+    res = {}
+    try:
+        for mode in (2, 1):
+            gpu.set_rcs_mode(mode)
+            assert gpu.upload(spec.f0, sc)
+            if mode == 2:
+                assert gpu.rcs_chunks() >= 16
+            gpu.optimize(None, max_iterations=2)
+            r = gpu.report
+            res[mode] = (r.iterations, r.attempts, r.err_initial, r.err_final, gpu.buffer(B.BUF_CORRECTIONS).copy())
+    finally:
+        gpu.set_rcs_mode(2)
+        gpu.upload(SCENES["tiny"].f0, sa.generate_scene(SCENES["tiny"]))  # release the 13 GB system
+    assert res[2][:3] == res[1][:3] and res[1][0] == 2
+    assert res[2][3] < res[2][2]
+    assert res[2][3] == pytest.approx(res[1][3], rel=1e-9)
+    assert rel_err(res[2][4], res[1][4]) < 1e-8
+
+
 # ------------------------------------------------------------------ sharded path, world size 1 on the GPU
 
 def test_allreduce_hook_with_device_pointers(orc, gpu):
