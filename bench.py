@@ -220,7 +220,7 @@ def main():
             "schur_phase": hbm(ab["schur"], per_attempt["ms_schur"], "k_schur_grouped", "k_schur", "k_env_zero",
                                "k_assemble"),
             "backsub_phase": hbm(ab["backsub"], per_attempt["ms_backsub"], "k_backsub_obs", "k_point_update"),
-            "error_phase": hbm(ab["error"], per_attempt["ms_error"], "k_error"),
+            "error_phase": hbm(ab["error"], per_attempt["ms_error"], "k_error", "k_error_staged"),
         }
         ms_syrk = per_attempt["ms_solve_syrk"]
         # flops actually executed by the MFMA trailing-update launches (= n^3/3 up to blocking when dense), counted by
