@@ -670,56 +670,75 @@ __global__ __launch_bounds__(256) void k_dinv(const CholBatch B)
 }
 
 // step K (descending, 256 rows): x_K = L_KK^-T y_K by four tile back-substitutions with the explicit tile inverses
-// (every workgroup, redundantly), then y_j -= sum_i L[256 K + i, j] x_K[i] for this workgroup's columns
-// j in [col_begin, 256 K).
+// (every workgroup, redundantly), then y_j -= sum_i L[256 K + i, j] x_K[i] for this workgroup's 64 columns
+// j in [col_begin, 256 K).  Every product is "one column per lane, the rows split over the four waves, partial sums
+// combined through LDS": short independent load chains instead of 64- and 256-long ones.
+#define BWD_COLS 64
 __global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholStep Kst, const CholStep cbeg)
 {
     __shared__ double sv[NBO];
+    __shared__ double sp[4][NBO - NB];
     const int64_t K = Kst.v[blockIdx.z], col_begin = cbeg.v[blockIdx.z];
     if (K < 0) return;
     const int64_t k0 = K * NBO;
     {
         const int64_t cols = k0 - col_begin;
-        if ((int64_t)blockIdx.x >= (cols > 0 ? (cols + 255) / 256 : 1)) return;
+        if ((int64_t)blockIdx.x >= (cols > 0 ? (cols + BWD_COLS - 1) / BWD_COLS : 1)) return;
     }
     const double* __restrict__ A = B.it[blockIdx.z].A;
     const double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
     double* __restrict__ y = B.it[blockIdx.z].y;
     double* __restrict__ x = B.it[blockIdx.z].x;
     const int64_t ld = B.it[blockIdx.z].ld;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     sv[t] = y[k0 + t];
     __syncthreads();
+#pragma unroll
     for (int sub = NBO / NB - 1; sub >= 0; --sub) {
-        // x_sub = Dinv_sub^T v_sub : thread (i = t >> 2, q = t & 3) sums m = q, q+4, ... then the quad reduces
-        const double* D = Dinv + (K * (NBO / NB) + sub) * NB * NB;
-        int i = t >> 2, q = t & 3;
-        double part = 0;
-#pragma unroll 4
-        for (int m = q; m < NB; m += 4) part += D[m * NB + i] * sv[sub * NB + m];
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        __syncthreads();
-        if (q == 0) sv[sub * NB + i] = part;
-        __syncthreads();
-        // v_c -= sum_i L[tile sub, col c] x_sub[i] for the columns c of the earlier tiles of this 256 block
-        if (t < sub * NB) {
-            const double* Lr = A + (k0 + sub * NB) * ld + k0 + t;
-            double acc = 0;
-#pragma unroll 8
-            for (int r = 0; r < NB; ++r) acc += Lr[(int64_t)r * ld] * sv[sub * NB + r];
-            sv[t] -= acc;
+        // x_sub = Dinv_sub^T v_sub : lane = entry i, wave wv sums m in [16 wv, 16 wv + 16) (coalesced rows of Dinv)
+        {
+            const double* D = Dinv + (K * (NBO / NB) + sub) * NB * NB + (int64_t)(16 * wv) * NB + lane;
+            double part = 0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) part = fma(D[m * NB], sv[sub * NB + 16 * wv + m], part);
+            sp[wv][lane] = part;
         }
+        __syncthreads();
+        if (t < NB) sv[sub * NB + t] = (sp[0][t] + sp[1][t]) + (sp[2][t] + sp[3][t]);
+        __syncthreads();
+        if (sub == 0) break;
+        // v_c -= sum_r L[tile sub row r, col c] x_sub[r] for the columns c of the earlier tiles of this 256 block
+        {
+            const double* Lr = A + (k0 + sub * NB + 16 * wv) * ld + k0 + lane;
+            double acc[NBO / NB - 1];
+#pragma unroll
+            for (int p = 0; p < NBO / NB - 1; ++p) acc[p] = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double xr = sv[sub * NB + 16 * wv + r];
+#pragma unroll
+                for (int p = 0; p < NBO / NB - 1; ++p)
+                    if (p < sub) acc[p] = fma(Lr[(int64_t)r * ld + p * NB], xr, acc[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < NBO / NB - 1; ++p)
+                if (p < sub) sp[wv][p * NB + lane] = acc[p];
+        }
+        __syncthreads();
+        if (t < sub * NB) sv[t] -= (sp[0][t] + sp[1][t]) + (sp[2][t] + sp[3][t]);
         __syncthreads();
     }
     if (blockIdx.x == 0) x[k0 + t] = sv[t];
-    int64_t j = col_begin + (int64_t)blockIdx.x * 256 + t;
-    if (j >= k0) return;
-    const double* Lc = A + k0 * ld + j;
+    const int64_t j = col_begin + (int64_t)blockIdx.x * BWD_COLS + lane;
     double acc = 0;
-#pragma unroll 8
-    for (int r = 0; r < NBO; ++r) acc += Lc[(int64_t)r * ld] * sv[r];
-    y[j] -= acc;
+    if (j < k0) {
+        const double* Lc = A + (k0 + 64 * wv) * ld + j;
+#pragma unroll 16
+        for (int r = 0; r < 64; ++r) acc = fma(Lc[(int64_t)r * ld], sv[64 * wv + r], acc);
+    }
+    sp[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && j < k0) y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
 // the solution must be all finite (the reference's allFinite check, :1912-1913)
@@ -818,7 +837,7 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
                 if (col_begin) cb = std::min(cb, col_begin[K * (NBO / NB) + q]);
             if (cb > K * NBO) cb = K * NBO;
             const int64_t cols = K * NBO - cb;
-            if (cols > 0) blocks = std::max(blocks, (cols + 255) / 256);
+            if (cols > 0) blocks = std::max(blocks, (cols + BWD_COLS - 1) / BWD_COLS);
             Kst.v[i] = K;
             cbeg.v[i] = cb;
         }
