@@ -365,10 +365,20 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
             sB[row][seg + t + 1] = vb.y;
         }
     }
-    __syncthreads();
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int wr = wave >> 1, wc = wave & 1;
     int lr = lane & 15, lk = lane >> 4;
+    // the C tile is read-modify-write: fetch it now, its latency hides under the barrier and the MFMAs
+    // (f64 16x16x4 accumulator map: col = lane & 15, row = (lane >> 4) + 4 * reg)
+    double* pc0 = A + (r0 + wr * 32 + lk) * ld + c0 + wc * 32 + lr;
+    double cv[2][2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cv[m][n][reg] = pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16];
+    __syncthreads();
     double4_t acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -385,18 +395,12 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
-    // f64 16x16x4 accumulator map: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                int64_t r = r0 + wr * 32 + m * 16 + lk + 4 * reg;
-                int64_t c = c0 + wc * 32 + n * 16 + lr;
-                double* pc = A + r * ld + c;
-                *pc = *pc - acc[m][n][reg];
-            }
+            for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
 }
 
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
@@ -535,15 +539,26 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){ 0, 0, 0, 0 };
-    for (int ch = 0; ch < NBO / NB; ++ch) {
-        const double* pa = A + (r0 + row) * ld + k0 + ch * NB + seg;
-        const double* pb = A + (c0 + row) * ld + k0 + ch * NB + seg;
-        double2 va[8], vb[8];
+    // the C tile is read-modify-write: fetch it first, its latency hides under the four K chunks
+    double* pc0 = A + (r0 + wr * 32 + lk) * ld + c0 + wc * 32 + lr;
+    double cv[2][2][4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            va[t] = reinterpret_cast<const double2*>(pa)[t];
-            vb[t] = reinterpret_cast<const double2*>(pb)[t];
-        }
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cv[m][n][reg] = pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16];
+    // software pipeline over the four 64-deep K chunks: the next chunk's global loads are in flight during the MFMAs
+    const double* pa = A + (r0 + row) * ld + k0 + seg;
+    const double* pb = A + (c0 + row) * ld + k0 + seg;
+    double2 va[8], vb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        va[t] = reinterpret_cast<const double2*>(pa)[t];
+        vb[t] = reinterpret_cast<const double2*>(pb)[t];
+    }
+#pragma unroll
+    for (int ch = 0; ch < NBO / NB; ++ch) {
         __syncthreads(); // previous chunk fully consumed
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -552,7 +567,14 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
             sB[row][seg + 2 * t] = vb[t].x;
             sB[row][seg + 2 * t + 1] = vb[t].y;
         }
-        __syncthreads();
+        if (ch + 1 < NBO / NB) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                va[t] = reinterpret_cast<const double2*>(pa + (ch + 1) * NB)[t];
+                vb[t] = reinterpret_cast<const double2*>(pb + (ch + 1) * NB)[t];
+            }
+        }
+        lds_barrier(); // LDS only: the prefetch stays in flight
 #pragma unroll
         for (int kk = 0; kk < NB / 4; ++kk) {
             double a0 = sA[wr * 32 + lr][kk * 4 + lk];
@@ -570,12 +592,7 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                int64_t r = r0 + wr * 32 + m * 16 + lk + 4 * reg;
-                int64_t c = c0 + wc * 32 + n * 16 + lr;
-                double* pc = A + r * ld + c;
-                *pc = *pc - acc[m][n][reg];
-            }
+            for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
 }
 
 // ---------------------------------------------------------------- backward substitution L^T x = y
