@@ -620,6 +620,11 @@ __global__ __launch_bounds__(256) void k_dinv(const CholBatch B)
         }
     }
     __syncthreads();
+    // reciprocals of the diagonal once, in parallel: an IEEE divide inside each of the 16 dependent substitution steps
+    // below would cost more than the rest of the kernel
+    __shared__ double sR[NB];
+    if (t < NB) sR[t] = 1.0 / sL[t][t];
+    __syncthreads();
     if (t < 64) { // thread (b, c): column c of the inverse of diagonal block b, right-looking in registers
         const int o = 16 * (t >> 4), c = t & 15;
         double acc[16];
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(256) void k_dinv(const CholBatch B)
         for (int i = 0; i < 16; ++i) acc[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const double z = (i >= c) ? acc[i] / sL[o + i][o + i] : 0.0;
+            const double z = (i >= c) ? acc[i] * sR[o + i] : 0.0;
             sZ[o + i][o + c] = z;
 #pragma unroll
             for (int k = i + 1; k < 16; ++k) acc[k] = fma(-sL[o + k][o + i], z, acc[k]);
