@@ -804,21 +804,28 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
                 for (int cc = 0; cc < 10; ++cc) sBuf[off + (5 * sh[s] + i) * w + 10 * sb[s] + cc] = acc[s][i][cc];
         }
         __syncthreads();
-        for (int e = tid; e < used; e += SRK_GRP_THREADS) {
-            // e -> block row a (off_a <= e < off_{a+1}), row r, block b, column c
-            int a = (int)((sqrtf(1.0f + 4.0f * ((float)e / 50.0f + (float)(a0 * (a0 + 1)))) - 1.0f) * 0.5f);
-            while (50 * ((a + 1) * (a + 2) - a0 * (a0 + 1)) <= e) ++a;
-            while (50 * (a * (a + 1) - a0 * (a0 + 1)) > e) --a;
-            int rem = e - 50 * (a * (a + 1) - a0 * (a0 + 1));
-            int w = 10 * (a + 1);
-            int r = rem / w, cw = rem - r * w;
-            int b = cw / 10, cc = cw - b * 10;
-            int64_t row = 10 * (int64_t)sF[a] + r, col = 10 * (int64_t)sF[b] + cc;
-            if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
+        // one wave per row of S: rows rho = 10 (a - a0) + r of the staged block rows go round the waves, the lanes walk
+        // the row's 10 (a + 1) columns (consecutive addresses where the frames are consecutive); the only divisions
+        // left are by the constant 10
+        {
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int rho = wv; rho < 10 * (a1 - a0); rho += SRK_GRP_THREADS / 64) {
+                const int a = a0 + rho / 10, r = rho - 10 * (a - a0);
+                const int w = 10 * (a + 1);
+                const int64_t row = 10 * (int64_t)sF[a] + r;
+                if (srk_is_fixed_var(row, d.comp)) continue;
+                const double* src = sBuf + 50 * (a * (a + 1) - a0 * (a0 + 1)) + r * w;
+                double* dst = S + row * d.ld;
+                for (int cw = lane; cw < w; cw += 64) {
+                    const int b = cw / 10, cc = cw - b * 10;
+                    const int64_t col = 10 * (int64_t)sF[b] + cc;
+                    if (srk_is_fixed_var(col, d.comp)) continue;
 #ifdef SRK_SCH_NOFLUSH
-            if (d.N >= 0) continue;
+                    if (d.N >= 0) continue;
 #endif
-            atomicAdd(&S[row * d.ld + col], -sBuf[e]);
+                    atomicAdd(&dst[col], -src[cw]);
+                }
+            }
         }
         a0 = a1;
     }
