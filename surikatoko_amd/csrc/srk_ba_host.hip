@@ -443,8 +443,9 @@ static int build_chunk_plan(srk_ba* h)
     if (!h->use_envelope || !h->use_chunks) return SRK_OK;
     int64_t maxdist = 0;
     for (int32_t j = 0; j < d.M; ++j) maxdist = std::max<int64_t>(maxdist, 10 * (int64_t)(j - h->min_cv[(size_t)j]) + 9);
-    int64_t sepw = maxdist <= 256 ? 256 : (maxdist <= 512 ? 512 : 0);
-    if (sepw == 0) return SRK_OK;
+    // separators at least one bandwidth wide, in units of the 256-column outer panel (k_bwd_border stages 2 sepw values)
+    const int64_t sepw = (maxdist + SRK_CHOL_NB - 1) / SRK_CHOL_NB * SRK_CHOL_NB;
+    if (sepw > SRK_MAX_SEPW) return SRK_OK;
     return make_plan(h, pl, d.ld, sepw, SRK_CHOL_NB, h->row_end_h, h->col_begin_h);
 }
 

@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_sep_reduce(const CholBatch B, int64_t s
 // A workgroup takes 64 columns; its four waves split the 2 sepw border rows and combine through LDS.
 __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs)
 {
-    __shared__ double sx[1024];
+    __shared__ double sx[2 * SRK_MAX_SEPW];
     __shared__ double sp[4][64];
     const int c = blockIdx.z;
     const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;

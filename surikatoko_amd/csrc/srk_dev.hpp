@@ -113,6 +113,7 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
 // ---- chunked (bordered block-diagonal) solve of a banded reduced camera system (srk_chol.hip) ----
 #include <vector>
 #define SRK_MAX_CHUNKS 32
+#define SRK_MAX_SEPW 1024 // widest separator (= covisibility bandwidth in variables) the chunked solve takes on
 struct SrkChunkPlan {
     int P = 0;                       // number of chunks; < 2 = not used
     int64_t sepw = 256;              // separator width (variables), >= bandwidth

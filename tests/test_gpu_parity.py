@@ -489,11 +489,11 @@ def test_allreduce_hook_with_device_pointers(orc, gpu):
 
 # ------------------------------------------------------------------ chunked (bordered block-diagonal) solve
 
-@pytest.mark.parametrize("n_frames,window", [(330, 8), (500, 12), (500, 30)])
+@pytest.mark.parametrize("n_frames,window", [(330, 8), (500, 12), (500, 30), (700, 70), (800, 95)])
 def test_chunked_solve_equals_single_chain(gpu, n_frames, window):
     """Banded reduced camera system cut into independent chunks + separator system (srk_chol_solve_chunked) against
     the single-chain skyline Cholesky and against numpy on the downloaded system.  window 30 needs 512-wide
-    separators."""
+    separators, 70 needs 768, 95 needs 1024 (the widest the chunked solve takes on)."""
     spec = sa.SceneSpec(n_frames=n_frames, grid_nx=60, grid_ny=40, vis_window=window)  # every frame well observed
     sc = sa.generate_scene(spec)
     c = 1e-3
