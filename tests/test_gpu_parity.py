@@ -523,6 +523,27 @@ def test_chunked_solve_equals_single_chain(gpu, n_frames, window):
     assert np.all(dc2[4:10] == 0) and dc2[15] == 0
 
 
+@pytest.mark.parametrize("n_frames", [26, 52, 77, 103, 128, 129, 154, 180, 205, 256, 257])
+def test_nested_plan_edge_sizes(gpu, n_frames):
+    """System sizes around every multiple of the 256-column outer panel (ld = 512 ... 2816): whatever plan the cost
+    model picks (none, one level, nested; chunks of one or two panels), the corrections must equal numpy's."""
+    spec = sa.SceneSpec(n_frames=n_frames, grid_nx=60, grid_ny=40, vis_window=8)  # every frame sees >= 7 landmarks
+    sc = sa.generate_scene(spec)
+    c = 1e-3
+    assert gpu.upload(spec.f0, sc)
+    gpu.phase_derivatives()
+    gpu.phase_schur(c)
+    S = gpu.buffer(B.BUF_RCS).reshape(10 * n_frames, 10 * n_frames)
+    rhs = gpu.buffer(B.BUF_RCS_RHS)
+    assert gpu.phase_solve()
+    gpu.phase_backsub(c)
+    dc = gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:]
+    x = np.linalg.solve(S, rhs)
+    for _ in range(3):
+        x = x + np.linalg.solve(S, rhs - S @ x)
+    assert rel_err(dc, x) < 1e-9, (n_frames, gpu.rcs_chunks())
+
+
 def test_chunked_end_to_end_matches_single_chain(gpu):
     spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
     sc = sa.generate_scene(spec)
