@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--config", default="C3_1kcam_100kpt")
     ap.add_argument("--drop", type=float, default=0.0,
                     help="remove this fraction of the observations at random (ragged tracks; not the headline workload)")
+    ap.add_argument("--schur-fp32", action="store_true",
+                    help="opt-in mixed precision (fp32 run sums in the Schur kernel); never the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
     ap.add_argument("--no-dense-probe", action="store_true")
@@ -123,6 +125,8 @@ def main():
 
     ba = sa.BundleAdjustmentKanatani(local_rank)
     ba.set_profile(0)  # the timed region carries no instrumentation; phases are timed in separate steps below
+    if args.schur_fp32:
+        ba.set_schur_precision(True)
     if world > 1:
         from surikatoko_amd.dist import make_allreduce_hook
         ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
@@ -290,7 +294,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not args.schur_fp32 else "f64 with fp32 Schur run sums (opt-in mixed precision)",
             "data": "synthetic",
             "config": {"workload": (f"ragged tracks ({args.drop:.0%} of the observations dropped) of " if args.drop > 0 else "") +
                                    f"{args.config}: {M} cams / {N_total} pts / {O_total} obs (circle-grid, "

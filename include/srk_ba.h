@@ -218,6 +218,13 @@ int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
 double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current mode / plan) */
 
+/* Opt-in mixed precision for the reduced camera system (the reference's suriko_scalar_type_string = f32 switch,
+ * suriko-engine/CMakeLists.txt:14-15, applied where it pays on this hardware): fp32 = 1 rounds W and E^-1 W to fp32
+ * when they are staged and accumulates each run of <= 128 landmarks with packed fp32 FMAs; the runs' sums, the frame
+ * blocks, the factorisation and everything else stay fp64.  Default 0 = the reference's fp64 arithmetic (the only
+ * mode the parity tests and the benchmark's headline use). */
+int srk_ba_set_schur_precision(srk_ba*, int fp32);
+
 /* device-time instrumentation of srk_ba_optimize / srk_ba_compute_inplace: 0 = none (report.ms_* stay 0 except
  * ms_total), 1 = one HIP event pair per phase (default; fills report.ms_*), 2 = additionally event pairs around
  * every MFMA trailing-update launch (fills report.ms_solve_syrk / solve_mfma_flops).  Every event costs a few

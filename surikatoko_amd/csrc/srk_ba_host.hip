@@ -77,6 +77,7 @@ struct srk_ba {
     hipEvent_t ev[16]{};
     std::vector<hipEvent_t> chol_ev;
     SrkSolveProf solve_prof; // event pairs / flops of the last profiled solve
+    bool schur_fp32 = false; // opt-in mixed precision: fp32 run sums in the grouped Schur kernel
     int profile_level = 1; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
     double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
     double last_hessian_factor = 0;
@@ -873,7 +874,7 @@ static int phase_schur(srk_ba* h, double c)
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->S),
                              P<double>(h->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
-                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide);
+                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->schur_fp32 ? 1 : 0);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());
@@ -1659,6 +1660,13 @@ double srk_ba_solve_mfma_flops(srk_ba* h)
     dry.dry = true; // walks the launch sequence of the current mode without launching anything
     launch_solve(h, &dry);
     return dry.flops;
+}
+
+int srk_ba_set_schur_precision(srk_ba* h, int fp32)
+{
+    if (!h || (fp32 != 0 && fp32 != 1)) return SRK_E_ARGS;
+    h->schur_fp32 = fp32 != 0;
+    return SRK_OK;
 }
 
 // knob for bench.py: event pairs around every MFMA trailing-update launch (report.ms_solve_syrk)

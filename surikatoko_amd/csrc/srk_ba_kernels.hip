@@ -605,7 +605,56 @@ static_assert(SRK_GRP_PRE * SRK_GRP_THREADS >= 30 * SRK_GRP_PB * SRK_GRP_MAXNF, 
 static_assert(SRK_GRP_NF1 * (SRK_GRP_NF1 + 1) <= SRK_GRP_THREADS && SRK_GRP_MAXNF * (SRK_GRP_MAXNF + 1) <= 2 * SRK_GRP_THREADS,
               "half blocks do not fit the thread slots");
 
-template <int SLOTS>
+// Arithmetic type of the accumulation.  double: the reference's arithmetic.  float (opt-in, srk_ba_set_schur_precision):
+// W and Y are rounded to fp32 when they are staged, the rank-3 updates run as packed fp32 FMAs (twice the fp64 rate,
+// half the LDS bytes and accumulator registers) over the <= 128 landmarks of a run, and the run's sums are added to
+// the fp64 system -- a mixed-precision reduced camera system.  LDS strides keep every 5-wide half
+// row and every 10-wide row on a 16-byte boundary.
+template <typename T> struct SchurLayout;
+template <> struct SchurLayout<double> { static constexpr int WH = 6, WM = 12, WS = 36, YM = 10, YS = 30; };
+template <> struct SchurLayout<float> { static constexpr int WH = 8, WM = 16, WS = 48, YM = 12, YS = 36; };
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// acc[5][10] += w[0..4] (x) y[0..9] for one point coordinate m
+__device__ __forceinline__ void schur_tile_update(double (&acc)[5][10], const double* wp, const double* yv)
+{
+    const double2 w01 = *reinterpret_cast<const double2*>(wp);
+    const double2 w23 = *reinterpret_cast<const double2*>(wp + 2);
+    const double wr[5] = { w01.x, w01.y, w23.x, w23.y, wp[4] };
+    const double2* yp = reinterpret_cast<const double2*>(yv);
+#pragma unroll
+    for (int h = 0; h < 5; ++h) {
+        const double2 y2 = yp[h];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            acc[i][2 * h] = fma(wr[i], y2.x, acc[i][2 * h]);
+            acc[i][2 * h + 1] = fma(wr[i], y2.y, acc[i][2 * h + 1]);
+        }
+    }
+}
+// fp32: the ten columns as five packed pairs (v_pk_fma_f32)
+__device__ __forceinline__ void schur_tile_update(float (&acc)[5][10], const float* wp, const float* yv)
+{
+    const float4_t w0123 = *reinterpret_cast<const float4_t*>(wp);
+    const float wr[5] = { w0123.x, w0123.y, w0123.z, w0123.w, wp[4] };
+    const float4_t y0123 = *reinterpret_cast<const float4_t*>(yv), y4567 = *reinterpret_cast<const float4_t*>(yv + 4);
+    const float2_t y89 = *reinterpret_cast<const float2_t*>(yv + 8);
+    const float2_t y2[5] = { { y0123.x, y0123.y }, { y0123.z, y0123.w }, { y4567.x, y4567.y }, { y4567.z, y4567.w }, y89 };
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float2_t w2 = { wr[i], wr[i] };
+#pragma unroll
+        for (int h = 0; h < 5; ++h) {
+            float2_t a2 = { acc[i][2 * h], acc[i][2 * h + 1] };
+            a2 = __builtin_elementwise_fma(w2, y2[h], a2);
+            acc[i][2 * h] = a2.x;
+            acc[i][2 * h + 1] = a2.y;
+        }
+    }
+}
+
+template <int SLOTS, typename T>
 __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
@@ -614,14 +663,15 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     const int32_t* __restrict__ grp_frames)
 {
     // one LDS arena: W | Y staging during the accumulation, then the staging buffer of the coalesced flush
-    constexpr int W_LM = SRK_GRP_MAXNF * SRK_GRP_WS, Y_LM = SRK_GRP_MAXNF * 30; // doubles per staged landmark
+    using L = SchurLayout<T>;
+    constexpr int W_LM = SRK_GRP_MAXNF * L::WS, Y_LM = SRK_GRP_MAXNF * L::YS; // elements per staged landmark
     constexpr int CAP = SRK_GRP_PB * (W_LM + Y_LM);
-    __shared__ __attribute__((aligned(16))) double sBuf[CAP];
+    __shared__ __attribute__((aligned(16))) T sBuf[CAP];
     __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
     __shared__ int32_t sF[SRK_GRP_MAXNF];
     __shared__ uint32_t sM[SRK_GRP_PB]; // ragged runs: the frame slots each staged landmark sees
-    double* const sW = sBuf;
-    double* const sY = sBuf + SRK_GRP_PB * W_LM;
+    T* const sW = sBuf;
+    T* const sY = sBuf + SRK_GRP_PB * W_LM;
     const int tid = threadIdx.x;
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
@@ -655,10 +705,10 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         while (a * (a + 1) / 2 > pi) --a;
         int b = pi - a * (a + 1) / 2;
         sa[s] = a; sb[s] = b; sh[s] = hf;
-        offW[s] = a * SRK_GRP_WS + 6 * hf;
-        offY[s] = b * 30;
+        offW[s] = a * L::WS + L::WH * hf;
+        offY[s] = b * L::YS;
     }
-    double acc[SLOTS][5][10];
+    T acc[SLOTS][5][10];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
@@ -679,8 +729,8 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         int pl = q / nf, a = q - pl * nf;
         int m = k / 10, r = k - 10 * m;
         qpos[j] = in ? q : (1 << 30);
-        koff[j] = 12 * m + r + (r >= 5);
-        loff[j] = in ? pl * W_LM + a * SRK_GRP_WS + koff[j] : 0; // uniform runs: landmark q / nf, slot q % nf
+        koff[j] = L::WM * m + r + (r >= 5 ? L::WH - 5 : 0);
+        loff[j] = in ? pl * W_LM + a * L::WS + koff[j] : 0; // uniform runs: landmark q / nf, slot q % nf
         gp[j] = W + (in ? (int64_t)k * d.Os + q : 0);
     }
     // Y stage map: item t = tid + i THREADS -> (staging slot pl, frame a, frame variable fv).  The same thread also
@@ -694,8 +744,8 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         int pl = t / (nf * 10), e = t - pl * nf * 10;
         int a = e / 10, fv = e - a * 10;
         ypl[i] = pl < SRK_GRP_PB ? pl : (1 << 30);
-        ywo[i] = pl * W_LM + a * SRK_GRP_WS + fv + (fv >= 5);
-        yyo[i] = pl * Y_LM + a * 30 + fv;
+        ywo[i] = pl * W_LM + a * L::WS + fv + (fv >= 5 ? L::WH - 5 : 0);
+        yyo[i] = pl * Y_LM + a * L::YS + fv;
         yrow[i] = e;
         ya[i] = a;
         racc[i] = 0;
@@ -715,7 +765,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
 #pragma unroll
             for (int j = 0; j < SRK_GRP_PRE; ++j)
                 if (qpos[j] < nq)
-                    pdst[j] = (obs_pt[oa + qpos[j]] - (int)(p0 + pb)) * W_LM + (int)obs_slot[oa + qpos[j]] * SRK_GRP_WS + koff[j];
+                    pdst[j] = (obs_pt[oa + qpos[j]] - (int)(p0 + pb)) * W_LM + (int)obs_slot[oa + qpos[j]] * L::WS + koff[j];
             if (tid < nbn) pmask = pt_mask[p0 + pb + tid];
         }
         return nq;
@@ -728,37 +778,37 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         if (!ragged) {
 #pragma unroll
             for (int j = 0; j < SRK_GRP_PRE; ++j)
-                if (qpos[j] < nq) sW[loff[j]] = pre[j];
+                if (qpos[j] < nq) sW[loff[j]] = (T)pre[j];
         } else {
 #pragma unroll
             for (int j = 0; j < SRK_GRP_PRE; ++j)
-                if (qpos[j] < nq) sW[pdst[j]] = pre[j];
+                if (qpos[j] < nq) sW[pdst[j]] = (T)pre[j];
             if (tid < nb) sM[tid] = pmask;
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < YI; ++i) {
             if (ypl[i] >= nb) continue;
-            double* wp = sW + ywo[i];
-            double* yp = sY + yyo[i];
+            T* wp = sW + ywo[i];
+            T* yp = sY + yyo[i];
             if (ragged && !((sM[ypl[i]] >> ya[i]) & 1u)) { // this landmark does not see this frame: zero blocks
-                wp[0] = wp[12] = wp[24] = 0.0;
-                yp[0] = yp[10] = yp[20] = 0.0;
+                wp[0] = wp[L::WM] = wp[2 * L::WM] = (T)0;
+                yp[0] = yp[L::YM] = yp[2 * L::YM] = (T)0;
                 continue;
             }
             const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl[i]]); // rows are 96 B: 16-byte aligned
             const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
-            const double w0 = wp[0], w1 = wp[12], w2 = wp[24];
-            yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
-            yp[10] = e23.y * w0 + e45.x * w1 + e45.y * w2;
-            yp[20] = e67.x * w0 + e67.y * w1 + e89.x * w2;
+            const double w0 = (double)wp[0], w1 = (double)wp[L::WM], w2 = (double)wp[2 * L::WM];
+            yp[0] = (T)(e01.x * w0 + e01.y * w1 + e23.x * w2);
+            yp[L::YM] = (T)(e23.y * w0 + e45.x * w1 + e45.y * w2);
+            yp[2 * L::YM] = (T)(e67.x * w0 + e67.y * w1 + e89.x * w2);
             racc[i] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
         }
         if (pb + SRK_GRP_PB < np) nq_next = prefetch(pb + SRK_GRP_PB); // in flight while this round is multiplied
         __syncthreads();
         for (int pl = 0; pl < nb; ++pl) {
-            const double* w = sW + pl * W_LM;
-            const double* yv = sY + pl * Y_LM;
+            const T* w = sW + pl * W_LM;
+            const T* yv = sY + pl * Y_LM;
 #ifdef SRK_SCH_NOACC
             if (d.N >= 0) continue;
 #endif
@@ -766,22 +816,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
             for (int s = 0; s < SLOTS; ++s) {
                 if (!act[s]) continue;
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const double* wp = w + offW[s] + 12 * m;
-                    const double2 w01 = *reinterpret_cast<const double2*>(wp);
-                    const double2 w23 = *reinterpret_cast<const double2*>(wp + 2);
-                    const double wr[5] = { w01.x, w01.y, w23.x, w23.y, wp[4] };
-                    const double2* yp = reinterpret_cast<const double2*>(yv + offY[s] + 10 * m);
-#pragma unroll
-                    for (int h = 0; h < 5; ++h) {
-                        const double2 y2 = yp[h];
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) {
-                            acc[s][i][2 * h] = fma(wr[i], y2.x, acc[s][i][2 * h]);
-                            acc[s][i][2 * h + 1] = fma(wr[i], y2.y, acc[s][i][2 * h + 1]);
-                        }
-                    }
-                }
+                for (int m = 0; m < 3; ++m) schur_tile_update(acc[s], w + offW[s] + L::WM * m, yv + offY[s] + L::YM * m);
             }
         }
     }
@@ -814,7 +849,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
                 const int w = 10 * (a + 1);
                 const int64_t row = 10 * (int64_t)sF[a] + r;
                 if (srk_is_fixed_var(row, d.comp)) continue;
-                const double* src = sBuf + 50 * (a * (a + 1) - a0 * (a0 + 1)) + r * w;
+                const T* src = sBuf + 50 * (a * (a + 1) - a0 * (a0 + 1)) + r * w;
                 double* dst = S + row * d.ld;
                 for (int cw = lane; cw < w; cw += 64) {
                     const int b = cw / 10, cc = cw - b * 10;
@@ -823,7 +858,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
 #ifdef SRK_SCH_NOFLUSH
                     if (d.N >= 0) continue;
 #endif
-                    atomicAdd(&dst[col], -src[cw]);
+                    atomicAdd(&dst[col], -(double)src[cw]);
                 }
             }
         }
@@ -841,15 +876,21 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
-                              const int32_t* grp_frames, int64_t n_groups, int64_t n_wide)
+                              const int32_t* grp_frames, int64_t n_groups, int64_t n_wide, int fp32_accumulate)
 {
     if (n_groups <= 0) return;
-    if (n_wide < n_groups)
-        hipLaunchKernelGGL(k_schur_grouped<1>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr, obs_pt,
-                           obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames);
-    if (n_wide > 0) // runs with more than SRK_GRP_NF1 frames: two half blocks per thread
-        hipLaunchKernelGGL(k_schur_grouped<2>, dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr, obs_pt,
-                           obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames);
+#define SRK_SCHUR_LAUNCH(SL, TY)                                                                                       \
+    hipLaunchKernelGGL((k_schur_grouped<SL, TY>), dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr, \
+                       obs_pt, obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames)
+    if (n_wide < n_groups) {
+        if (fp32_accumulate) SRK_SCHUR_LAUNCH(1, float);
+        else SRK_SCHUR_LAUNCH(1, double);
+    }
+    if (n_wide > 0) { // runs with more than SRK_GRP_NF1 frames: two half blocks per thread
+        if (fp32_accumulate) SRK_SCHUR_LAUNCH(2, float);
+        else SRK_SCHUR_LAUNCH(2, double);
+    }
+#undef SRK_SCHUR_LAUNCH
 }
 
 // G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark

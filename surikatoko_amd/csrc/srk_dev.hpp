@@ -59,7 +59,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               double* S, double* rhs, const int32_t* grp_first, const int32_t* grp_count,
                               const int32_t* grp_nf /* size of the run's frame set; negative = ragged run */,
                               const int32_t* grp_frames /* [n_groups][SRK_GRP_MAXNF_HOST] */, int64_t n_groups,
-                              int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */);
+                              int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */,
+                              int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
                          double ident /* diagonal of fixed / padding variables */);
 void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,

@@ -654,3 +654,41 @@ def test_f32_boundary_matches_f64_run_on_the_same_rounded_inputs(gpu):
     with pytest.raises(ValueError):
         gpu.ComputeInplaceF32(spec.f0, sc.points, f32["cam_R"], f32["cam_T"], f32["K"], sc.shared_k, sc.row_ptr,
                               sc.obs_frame, f32["obs_uv"])
+
+
+# ------------------------------------------------------------------ opt-in mixed precision
+
+@pytest.mark.parametrize("name", ["ragged_wave", "pixel_noise", "ragged_20"])
+def test_fp32_schur_run_sums_stay_close_to_fp64(orc, gpu, name):
+    """srk_ba_set_schur_precision(1): W and E^-1 W rounded to fp32, packed fp32 FMAs over a run, fp64 everywhere else.
+    Tolerance table of this mode (against the fp64 path on the same inputs): reduced camera system 2e-6 of its largest
+    entry, one-step corrections 2e-3, the LM loop must take the same accept / reject decisions over the first
+    iterations and land within 1e-4 of the fp64 error."""
+    if name in SCENES:
+        spec, sc = SCENES[name], sa.generate_scene(SCENES[name])
+    else:
+        spec, frac = RAGGED[name]
+        sc = sa.drop_observations(sa.generate_scene(spec), frac, seed=7)
+    res = {}
+    try:
+        for fp32 in (False, True):
+            gpu.set_schur_precision(fp32)
+            assert gpu.upload(spec.f0, sc)
+            gpu.phase_derivatives()
+            gpu.phase_schur(1e-3)
+            S = gpu.buffer(B.BUF_RCS).copy()
+            assert gpu.phase_solve()
+            gpu.phase_backsub(1e-3)
+            corr = gpu.buffer(B.BUF_CORRECTIONS).copy()
+            s2 = sc.copy()
+            gpu.ComputeInplace(spec.f0, s2, None, 4)
+            res[fp32] = (S, corr, gpu.report.iterations, gpu.report.attempts, gpu.report.err_final)
+    finally:
+        gpu.set_schur_precision(False)
+    S64, c64, it64, at64, e64 = res[False]
+    S32, c32, it32, at32, e32 = res[True]
+    assert np.abs(S32 - S64).max() < 2e-6 * np.abs(S64).max()
+    assert np.abs(S32 - S64).max() > 0  # the switch really changes the arithmetic
+    assert rel_err(c32, c64) < 2e-3
+    assert (it32, at32) == (it64, at64)
+    assert e32 == pytest.approx(e64, rel=1e-4)
