@@ -52,7 +52,7 @@ struct srk_ba {
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
     DevBuf grp_first, grp_count, grp_nf, grp_frames, obs_slot, pt_mask, gen_list, wg_jmin;
     DevBuf sc_pts, sc_R, sc_T, sc_K, sc_cam, sc_frame, sc_pt, sc_uv, sc_partial, sc_out; // standalone scoring path
-    int64_t n_groups = 0, n_groups_wide = 0, n_generic = 0;
+    int64_t n_groups = 0, n_groups_wide = 0, n_groups_mid = 0, n_generic = 0;
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
@@ -578,7 +578,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     std::vector<int32_t> grp_first, grp_count, grp_nf, grp_frames, gen_list;
     std::vector<uint8_t> obs_slot((size_t)O, 0);
     std::vector<uint32_t> pt_mask((size_t)N, 0);
-    int64_t n_wide = 0;
+    int64_t n_wide = 0, n_mid = 0;
     {
         std::vector<int32_t> uni, merged;
         for (int64_t i = 0; i < N;) {
@@ -617,11 +617,13 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             grp_nf.push_back(uniform ? (int32_t)uni.size() : -(int32_t)uni.size()); // negative = ragged run
             for (int k = 0; k < SRK_GRP_MAXNF_HOST; ++k) grp_frames.push_back(k < (int)uni.size() ? uni[(size_t)k] : -1);
             if ((int64_t)uni.size() > SRK_GRP_NF1_HOST) ++n_wide;
+            else if ((int64_t)uni.size() > SRK_WS_NF_HOST) ++n_mid;
             i = j;
         }
     }
     h->n_groups = (int64_t)grp_first.size();
     h->n_groups_wide = n_wide;
+    h->n_groups_mid = n_mid;
     h->n_generic = (int64_t)gen_list.size();
     SrkDims d{};
     d.N = N;
@@ -874,7 +876,7 @@ static int phase_schur(srk_ba* h, double c)
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->S),
                              P<double>(h->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
-                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->schur_fp32 ? 1 : 0);
+                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());

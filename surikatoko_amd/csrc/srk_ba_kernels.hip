@@ -660,7 +660,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
-    const int32_t* __restrict__ grp_frames)
+    const int32_t* __restrict__ grp_frames, int nf_skip /* runs with at most this many frames belong to k_schur_ws */)
 {
     // one LDS arena: W | Y staging during the accumulation, then the staging buffer of the coalesced flush
     using L = SchurLayout<T>;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     const int nfu = grp_nf[blockIdx.x];
     const bool ragged = nfu < 0;
     const int nf = ragged ? -nfu : nfu;
-    if ((SLOTS == 1) != (nf <= SRK_GRP_NF1)) return; // the other instantiation takes this run
+    if ((SLOTS == 1) != (nf <= SRK_GRP_NF1) || nf <= nf_skip) return; // another kernel takes this run
     if (tid < nf) sF[tid] = grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid];
     if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
         double Einv[9], g[3];
@@ -873,24 +873,269 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     }
 }
 
+// ------------------------------------------------------------------ K3w: the same, with a dedicated loader wave
+// k_schur_grouped spends about as long staging (global -> LDS, Y = E^-1 W, three barriers a round) as multiplying,
+// and with 214 accumulator-heavy VGPRs only one workgroup fits a CU, so nothing overlaps the two.  A run over at most
+// SRK_WS_NF frames has nf (nf + 1) <= 420 half blocks = the lanes of waves 0..6: wave 7 does nothing but stage.  Here
+// it stages round r + 1 into the second half of a double-buffered LDS arena (and already has round r + 2's global
+// loads in flight) while waves 0..6 multiply round r -- one barrier per round, the multiply never waits for memory.
+#define SRK_WS_NF 20
+template <typename T>
+__global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
+    SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
+    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
+    const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
+    const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
+    const int32_t* __restrict__ grp_frames)
+{
+    using L = SchurLayout<T>;
+    constexpr int PB = SRK_GRP_PB;
+    constexpr int W_LM = SRK_WS_NF * L::WS, Y_LM = SRK_WS_NF * L::YS; // elements per staged landmark
+    constexpr int BUF = PB * (W_LM + Y_LM);                           // one staging buffer
+    constexpr int CAP = 2 * BUF;                                      // the flush uses both
+    __shared__ __attribute__((aligned(16))) T sBuf[CAP];
+    __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
+    __shared__ double sRhs[SRK_WS_NF * 10];
+    __shared__ int32_t sF[SRK_WS_NF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t p0 = grp_first[blockIdx.x];
+    const int np = grp_count[blockIdx.x];
+    const int nfu = grp_nf[blockIdx.x];
+    const bool ragged = nfu < 0;
+    const int nf = ragged ? -nfu : nfu;
+    if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
+    if (tid < nf) sF[tid] = grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid];
+    if (tid < nf * 10) sRhs[tid] = 0.0;
+    if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
+        double Einv[9], g[3];
+        bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
+    }
+    const int R = (np + PB - 1) / PB;
+    const int nf10 = nf * 10;
+    // one pass of the flush streams the staged block rows a0 .. a1 - 1 out of LDS: one wave per row of S, the lanes walk
+    // the row's 10 (a + 1) columns
+    auto flush_stream = [&](int a0, int a1) {
+        for (int rho = wv; rho < 10 * (a1 - a0); rho += SRK_GRP_THREADS / 64) {
+            const int a = a0 + rho / 10, r = rho - 10 * (a - a0);
+            const int w = 10 * (a + 1);
+            const int64_t row = 10 * (int64_t)sF[a] + r;
+            if (srk_is_fixed_var(row, d.comp)) continue;
+            const T* src = sBuf + 50 * (a * (a + 1) - a0 * (a0 + 1)) + r * w;
+            double* dst = S + row * d.ld;
+            for (int cw = lane; cw < w; cw += 64) {
+                const int b = cw / 10, cc = cw - b * 10;
+                const int64_t col = 10 * (int64_t)sF[b] + cc;
+                if (srk_is_fixed_var(col, d.comp)) continue;
+#ifdef SRK_SCH_NOFLUSH
+                if (d.N >= 0) continue;
+#endif
+                atomicAdd(&dst[col], -(double)src[cw]);
+            }
+        }
+    };
+    auto flush_span = [&](int a0, int& a1) { // block rows that fit the arena from a0 on
+        int used = 0;
+        a1 = a0;
+        while (a1 < nf && used + 100 * (a1 + 1) <= CAP) { used += 100 * (a1 + 1); ++a1; }
+    };
+    __syncthreads(); // sE, sF, sRhs are visible
+    // The two roles are two separate code paths with the same barrier sequence (R + 1 for the rounds, two per flush
+    // pass), so that the accumulators live only in the multiplier path and the prefetch registers only in the loader's.
+    if (wv == 7) {
+        // ---- loader.  A round's observations are contiguous, at most PB nf <= 80: the lane covers q = lane and
+        // q = lane + 64; for each it moves the 30 W values (k-major in memory: one coalesced load per k).
+        const unsigned magic_nf = (65536u + nf - 1) / nf; // q < 128
+        double pre[30][2];
+        int dq[2]; // LDS offset of (staged landmark, frame slot) for the two q of this lane
+        int nq_pre = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { // uniform runs: landmark q / nf, slot q % nf
+            const int q = lane + 64 * h;
+            const int pl = (int)((q * magic_nf) >> 16);
+            dq[h] = pl * W_LM + (q - pl * nf) * L::WS;
+        }
+        auto load_round = [&](int r) { // global loads of round r into `pre` (left in flight)
+            const int pb = r * PB;
+            const int nbn = np - pb < PB ? np - pb : PB;
+            const int64_t oa = row_ptr[p0 + pb];
+            nq_pre = (int)(row_ptr[p0 + pb + nbn] - oa);
+            const double* base = W + oa + lane;
+#pragma unroll
+            for (int k = 0; k < 30; ++k) {
+                pre[k][0] = lane < nq_pre ? base[(int64_t)k * d.Os] : 0.0;
+                pre[k][1] = lane + 64 < nq_pre ? base[(int64_t)k * d.Os + 64] : 0.0;
+            }
+            if (ragged) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = lane + 64 * h;
+                    if (q < nq_pre) dq[h] = (obs_pt[oa + q] - (int)(p0 + pb)) * W_LM + (int)obs_slot[oa + q] * L::WS;
+                }
+            }
+        };
+        auto stage_round = [&](T* bw) { // `pre` -> W in LDS (Y = E^-1 W is the multipliers' first step of the round)
+#pragma unroll
+            for (int k = 0; k < 30; ++k) {
+                const int m = k / 10, rr = k - 10 * m;
+                const int ko = L::WM * m + rr + (rr >= 5 ? L::WH - 5 : 0);
+                if (lane < nq_pre) bw[dq[0] + ko] = (T)pre[k][0];
+                if (lane + 64 < nq_pre) bw[dq[1] + ko] = (T)pre[k][1];
+            }
+        };
+        load_round(0);
+        stage_round(sBuf);
+        if (R > 1) load_round(1);
+        __syncthreads();
+        for (int r = 0; r < R; ++r) {
+            __syncthreads(); // the multipliers' Y of round r: pass at once, they must not wait for the staging below
+            if (r + 1 < R) {
+#ifndef SRK_WS_NOSTAGE
+                stage_round(sBuf + ((r + 1) & 1) * BUF);
+#endif
+#ifndef SRK_WS_NOLOAD
+                if (r + 2 < R) load_round(r + 2);
+#endif
+            }
+            __syncthreads(); // their products of round r
+        }
+        for (int a0 = 0; a0 < nf;) {
+            int a1;
+            flush_span(a0, a1);
+            __syncthreads();
+            __syncthreads();
+            flush_stream(a0, a1);
+            a0 = a1;
+        }
+    } else {
+        // ---- multipliers: half block u = tid -> (block pair (a, b), b <= a ; rows 5 hf .. 5 hf + 4)
+        const bool act = tid < nf * (nf + 1);
+        int sa, sb, sh;
+        {
+            int pi = act ? tid >> 1 : 0;
+            sh = act ? tid & 1 : 0;
+            sa = (int)((sqrtf(8.0f * (float)pi + 1.0f) - 1.0f) * 0.5f);
+            while ((sa + 1) * (sa + 2) / 2 <= pi) ++sa;
+            while (sa * (sa + 1) / 2 > pi) --sa;
+            sb = pi - sa * (sa + 1) / 2;
+        }
+        const int offW = sa * L::WS + L::WH * sh, offY = sb * L::YS;
+        T acc[5][10];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int cc = 0; cc < 10; ++cc) acc[i][cc] = 0;
+        // Y stage map: item t = tid + 448 i -> (staging slot pl, frame a, frame variable fv); the same thread keeps the
+        // rhs term W^T (E^-1 g) of its items (the PB slots of one (a, fv) meet in sRhs at the end)
+        constexpr int YI = (PB * SRK_WS_NF * 10 + 447) / 448;
+        int ypl[YI], ywo[YI], yyo[YI], ye[YI];
+        double racc[YI];
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            const int t = tid + 448 * i;
+            const int pl = t / nf10, e = t - pl * nf10;
+            const int a = e / 10, fv = e - a * 10;
+            ypl[i] = pl < PB ? pl : (1 << 30);
+            ywo[i] = pl * W_LM + a * L::WS + fv + (fv >= 5 ? L::WH - 5 : 0);
+            yyo[i] = pl * Y_LM + a * L::YS + fv;
+            ye[i] = e;
+            racc[i] = 0;
+        }
+        __syncthreads();
+        for (int r = 0; r < R; ++r) {
+            T* bw = sBuf + (r & 1) * BUF;
+            T* by = bw + PB * W_LM;
+            const int pb = r * PB;
+            const int nb = np - pb < PB ? np - pb : PB;
+#pragma unroll
+            for (int i = 0; i < YI; ++i) {
+                if (ypl[i] >= nb) continue;
+                T* wp = bw + ywo[i];
+                T* yp = by + yyo[i];
+                if (ragged && !((pt_mask[p0 + pb + ypl[i]] >> (ye[i] / 10)) & 1u)) { // landmark misses this frame: zeros
+                    wp[0] = wp[L::WM] = wp[2 * L::WM] = (T)0;
+                    yp[0] = yp[L::YM] = yp[2 * L::YM] = (T)0;
+                    continue;
+                }
+                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl[i]]); // rows are 96 B: 16-byte aligned
+                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
+                const double w0 = (double)wp[0], w1 = (double)wp[L::WM], w2 = (double)wp[2 * L::WM];
+                yp[0] = (T)(e01.x * w0 + e01.y * w1 + e23.x * w2);
+                yp[L::YM] = (T)(e23.y * w0 + e45.x * w1 + e45.y * w2);
+                yp[2 * L::YM] = (T)(e67.x * w0 + e67.y * w1 + e89.x * w2);
+                racc[i] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
+            }
+            __syncthreads();
+            if (act) {
+                for (int pl = 0; pl < nb; ++pl) {
+#ifdef SRK_SCH_NOACC
+                    if (d.N >= 0) continue;
+#endif
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        schur_tile_update(acc, bw + pl * W_LM + offW + L::WM * m, by + pl * Y_LM + offY + L::YM * m);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < YI; ++i)
+            if (ypl[i] < PB && ypl[i] < np) atomicAdd(&sRhs[ye[i]], racc[i]);
+        // flush: the tiles are transposed through LDS a few block rows at a time
+        for (int a0 = 0; a0 < nf;) {
+            int a1;
+            flush_span(a0, a1);
+            __syncthreads();
+            if (act && sa >= a0 && sa < a1) {
+                int off = 50 * (sa * (sa + 1) - a0 * (a0 + 1)); // sum_{a'=a0}^{a-1} 100 (a' + 1)
+                int w = 10 * (sa + 1);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int cc = 0; cc < 10; ++cc) sBuf[off + (5 * sh + i) * w + 10 * sb + cc] = acc[i][cc];
+            }
+            __syncthreads();
+            flush_stream(a0, a1);
+            a0 = a1;
+        }
+    }
+    // rhs += sum F^T E^-1 g (the multipliers' sRhs adds precede the flush's barriers; nf >= 1 means at least one pass)
+    if (tid < nf10) {
+        const int a = tid / 10, r = tid - a * 10;
+        const int64_t row = 10 * (int64_t)sF[a] + r;
+        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], sRhs[tid]);
+    }
+}
+
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
-                              const int32_t* grp_frames, int64_t n_groups, int64_t n_wide, int fp32_accumulate)
+                              const int32_t* grp_frames, int64_t n_groups, int64_t n_wide, int64_t n_mid,
+                              int fp32_accumulate)
 {
     if (n_groups <= 0) return;
-#define SRK_SCHUR_LAUNCH(SL, TY)                                                                                       \
-    hipLaunchKernelGGL((k_schur_grouped<SL, TY>), dim3((unsigned)n_groups), dim3(SRK_GRP_THREADS), 0, s, d, c, row_ptr, \
-                       obs_pt, obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames)
-    if (n_wide < n_groups) {
-        if (fp32_accumulate) SRK_SCHUR_LAUNCH(1, float);
-        else SRK_SCHUR_LAUNCH(1, double);
+    // the loader-wave kernel pays when the multiply of a round is long enough to hide the staging: fp64 only (with the
+    // packed fp32 products a round is too short and the single-role kernel is faster).  SRK_SCHUR_NO_WS: development.
+    static const bool env_no_ws = getenv("SRK_SCHUR_NO_WS") != nullptr;
+    const bool no_ws = env_no_ws || fp32_accumulate;
+    const int nf_skip = no_ws ? 0 : SRK_WS_NF;
+#define SRK_SCHUR_ARGS d, c, row_ptr, obs_pt, obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames
+    const dim3 grid((unsigned)n_groups), block(SRK_GRP_THREADS);
+    if (!no_ws && n_wide + n_mid < n_groups) // runs over at most SRK_WS_NF frames: loader-wave kernel
+        hipLaunchKernelGGL(k_schur_ws<double>, grid, block, 0, s, SRK_SCHUR_ARGS);
+    if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread
+        if (fp32_accumulate) hipLaunchKernelGGL((k_schur_grouped<1, float>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
+        else hipLaunchKernelGGL((k_schur_grouped<1, double>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
     }
-    if (n_wide > 0) { // runs with more than SRK_GRP_NF1 frames: two half blocks per thread
-        if (fp32_accumulate) SRK_SCHUR_LAUNCH(2, float);
-        else SRK_SCHUR_LAUNCH(2, double);
+    if (n_wide > 0) { // more than SRK_GRP_NF1 frames: two half blocks per thread
+        if (fp32_accumulate) hipLaunchKernelGGL((k_schur_grouped<2, float>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
+        else hipLaunchKernelGGL((k_schur_grouped<2, double>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
     }
-#undef SRK_SCHUR_LAUNCH
+#undef SRK_SCHUR_ARGS
 }
 
 // G (block diagonal of the frame blocks, diagonal * (1+c), gauge rows/cols dropped) is added after the landmark

@@ -53,6 +53,7 @@ void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* 
 #define SRK_GRP_MAXNF_HOST 24   // must match SRK_GRP_MAXNF in srk_ba_kernels.hip
 #define SRK_GRP_MAXPTS_HOST 128 // landmarks per workgroup run
 #define SRK_GRP_NF1_HOST 21     // must match SRK_GRP_NF1
+#define SRK_WS_NF_HOST 20       // must match SRK_WS_NF (runs the loader-wave kernel takes)
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
                               const uint8_t* obs_slot /* [O] slot of the observation's frame in its run's frame set */,
                               const uint32_t* pt_mask /* [N] slots a landmark sees */, const double* W, const double* Vg,
@@ -60,6 +61,7 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               const int32_t* grp_nf /* size of the run's frame set; negative = ragged run */,
                               const int32_t* grp_frames /* [n_groups][SRK_GRP_MAXNF_HOST] */, int64_t n_groups,
                               int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */,
+                              int64_t n_mid /* runs with SRK_WS_NF_HOST < frames <= SRK_GRP_NF1_HOST */,
                               int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
                          double ident /* diagonal of fixed / padding variables */);
