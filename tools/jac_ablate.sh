@@ -3,9 +3,9 @@
 set -e
 cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
 cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
-for abl in NONE SRK_JF_V_SHUFFLE SRK_JF_CAM_GLOBAL "SRK_JF_V_SHUFFLE -DSRK_JF_CAM_GLOBAL"; do
+for abl in ${ABLS:-NONE}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -D$abl -c srk_ba_kernels.hip -o /tmp/k_abl.o 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so /tmp/k_abl.o srk_chol.o srk_ba_host.o srk_scene.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so /tmp/k_abl.o srk_chol.o srk_ba_host.o srk_scene.o srk_io.o
   (cd "$GRAFT_REPO_ROOT" && python - <<PY
 import surikatoko_amd as sa, time
 spec=sa.CONFIGS["C3_1kcam_100kpt"]; sc=sa.generate_scene(spec)
