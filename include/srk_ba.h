@@ -218,6 +218,12 @@ int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
 double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current mode / plan) */
 
+/* Speculative attempts (default on; takes effect at the next upload): with one rank and the instrumentation off
+ * (srk_ba_set_profile 0, the default) the LM loop runs the next damping factor on a second stream beside the current
+ * one and judges the attempts in the reference's order, so results are those of the sequential loop; costs a second
+ * reduced camera system in memory.  0 = strictly one attempt at a time. */
+int srk_ba_set_speculation(srk_ba*, int on);
+
 /* Opt-in mixed precision for the reduced camera system (the reference's suriko_scalar_type_string = f32 switch,
  * suriko-engine/CMakeLists.txt:14-15, applied where it pays on this hardware): fp32 = 1 rounds W and E^-1 W to fp32
  * when they are staged and accumulates each run of <= 128 landmarks with packed fp32 FMAs; the runs' sums, the frame
@@ -225,10 +231,10 @@ double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates o
  * mode the parity tests and the benchmark's headline use). */
 int srk_ba_set_schur_precision(srk_ba*, int fp32);
 
-/* device-time instrumentation of srk_ba_optimize / srk_ba_compute_inplace: 0 = none (report.ms_* stay 0 except
- * ms_total), 1 = one HIP event pair per phase (default; fills report.ms_*), 2 = additionally event pairs around
+/* device-time instrumentation of srk_ba_optimize / srk_ba_compute_inplace: 0 = none (default; report.ms_* stay 0
+ * except ms_total), 1 = one HIP event pair per phase (fills report.ms_*), 2 = additionally event pairs around
  * every MFMA trailing-update launch (fills report.ms_solve_syrk / solve_mfma_flops).  Every event costs a few
- * microseconds on the stream. */
+ * microseconds on the stream, and levels >= 1 serialise the attempts (no speculation).  Default 0. */
 int srk_ba_set_profile(srk_ba*, int level);
 
 /* dense SPD solve A x = b on the device (the reduced-camera-system solver on its own; A row-major

@@ -277,12 +277,16 @@ class BundleAdjustmentKanatani:
     def reset(self):
         self._raise(self._lib.srk_ba_reset_scene(C.c_void_p(self._h)))
 
+    def set_speculation(self, on=True):
+        """Run the next damping factor beside the current attempt (one rank, instrumentation off); next upload."""
+        self._raise(self._lib.srk_ba_set_speculation(C.c_void_p(self._h), C.c_int(int(bool(on)))))
+
     def set_schur_precision(self, fp32=False):
         """Opt-in mixed precision: fp32 run sums in the grouped Schur kernel (everything else stays fp64)."""
         self._raise(self._lib.srk_ba_set_schur_precision(C.c_void_p(self._h), C.c_int(int(bool(fp32)))))
 
     def set_profile(self, level=2):
-        """0 = no device events, 1 = per-phase events (default of the library), 2 / True = + MFMA update events."""
+        """0 = no device events (default of the library), 1 = per-phase events, 2 / True = + MFMA update events."""
         if level is True:
             level = 2
         self._raise(self._lib.srk_ba_set_profile(C.c_void_p(self._h), C.c_int(int(level))))

@@ -44,10 +44,10 @@ struct srk_ba {
     bool normalized_on_upload = false;
 
     // device buffers
-    DevBuf pts[2], camR[2], camT[2], K, cam[2];
+    DevBuf pts[3], camR[3], camT[3], K, cam[3]; // the current scene + one trial scene per attempt slot
     DevBuf pts0, camR0, camT0; // copy of the uploaded (normalised) scene for srk_ba_reset_scene
     DevBuf row_ptr, obs_frame, obs_pt, obs_uv, col_ptr, fobs_pt, fobs_uv;
-    DevBuf W, Vg, Ug, S, rhs, wy, dc, acc, dx, err_partial, err_out, info, scratch;
+    DevBuf W, Vg, Ug, scratch;
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
     DevBuf grp_first, grp_count, grp_nf, grp_frames, obs_slot, pt_mask, gen_list, wg_jmin;
@@ -57,15 +57,32 @@ struct srk_ba {
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
     std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
-    DevBuf env_col, env_off, packed, dinv, band_col, band_off;
+    DevBuf env_col, env_off, packed, band_col, band_off;
     int64_t env_packed = 0, band_packed = 0; // doubles inside the factorisation skyline / the pre-factorisation band
     bool use_envelope = true;
     // chunked solve of a banded system (srk_chol.hip): plan + its buffers
     bool use_chunks = true;
-    SrkChunkPlan plan;
-    std::vector<DevBuf> plan_bufs;
-    std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
-    int cur = 0; // index of the current scene buffers; 1-cur = trial
+    // Everything one LM attempt writes lives in an attempt slot: the reduced camera system and its solver plan, the
+    // corrections, the trial scene, the status words, and the stream it runs on.  Two slots let the loop run the next
+    // damping factor speculatively beside the current one (the solve is a latency chain that leaves the chip idle).
+    struct Attempt {
+        DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv;
+        SrkChunkPlan plan;
+        std::vector<DevBuf> plan_bufs;
+        std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
+        SrkSolveProf solve_prof;     // event pairs / flops of the last profiled solve
+        double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        int trial = 1;               // index of this slot's trial scene buffers
+        bool allocated = false;
+    };
+    Attempt att[2];
+    Attempt* A = &att[0]; // the slot the phase functions work on (select_attempt)
+    hipStream_t main_stream = nullptr; // = att[0].stream
+    hipEvent_t ev_jac = nullptr;       // derivatives done (the second slot's stream waits for it)
+    bool speculate = true;             // single rank, instrumentation off: run two damping factors side by side
+    int cur = 0; // index of the current scene buffers
 
     // multi-GPU exchange
     srk_allreduce_fn allreduce = nullptr;
@@ -76,10 +93,9 @@ struct srk_ba {
     // timing
     hipEvent_t ev[16]{};
     std::vector<hipEvent_t> chol_ev;
-    SrkSolveProf solve_prof; // event pairs / flops of the last profiled solve
     bool schur_fp32 = false; // opt-in mixed precision: fp32 run sums in the grouped Schur kernel
-    int profile_level = 1; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
-    double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
+    int profile_level = 0; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
+    int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
 };
 
@@ -142,16 +158,28 @@ srk_ba* srk_ba_create(int device_id)
         delete h;
         return nullptr;
     }
-    for (auto& e : h->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            delete h;
-            return nullptr;
-        }
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_back), 64, hipHostMallocDefault) != hipSuccess) {
+    h->main_stream = h->stream;
+    h->att[0].stream = h->stream;
+    h->att[0].trial = 1;
+    h->att[1].trial = 2;
+    bool ok = hipStreamCreateWithFlags(&h->att[1].stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_jac, hipEventDisableTiming) == hipSuccess;
+    for (auto& a : h->att)
+        ok = ok && hipEventCreateWithFlags(&a.done, hipEventDisableTiming) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&a.host_back), 64, hipHostMallocDefault) == hipSuccess;
+    for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) {
         delete h;
         return nullptr;
     }
     return h;
+}
+
+// the phase functions work on h->A and enqueue on h->stream: point both at one attempt slot
+static void select_attempt(srk_ba* h, int slot)
+{
+    h->A = &h->att[slot];
+    h->stream = h->A->stream;
 }
 
 void srk_ba_destroy(srk_ba* h)
@@ -159,20 +187,27 @@ void srk_ba_destroy(srk_ba* h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->camR[0], &h->camR[1], &h->camT[0], &h->camT[1], &h->K, &h->cam[0],
-                      &h->cam[1], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr, &h->obs_frame, &h->obs_pt, &h->obs_uv,
-                      &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug, &h->S, &h->rhs, &h->wy, &h->dc,
-                      &h->acc, &h->dx, &h->err_partial, &h->err_out, &h->info, &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
-                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->dinv, &h->band_col, &h->band_off };
+    if (h->att[1].stream) hipStreamSynchronize(h->att[1].stream);
+    DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->pts[2], &h->camR[0], &h->camR[1], &h->camR[2], &h->camT[0], &h->camT[1],
+                      &h->camT[2], &h->K, &h->cam[0], &h->cam[1], &h->cam[2], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
+                      &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
+                      &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
+                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->band_col, &h->band_off };
     for (DevBuf* b : all) dev_free(*b);
-    for (DevBuf& b : h->plan_bufs) dev_free(b);
+    for (auto& a : h->att) {
+        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv }) dev_free(*b);
+        for (DevBuf& b : a.plan_bufs) dev_free(b);
+        if (a.host_back) hipHostFree(a.host_back);
+        if (a.done) hipEventDestroy(a.done);
+    }
     for (DevBuf* b : { &h->sc_pts, &h->sc_R, &h->sc_T, &h->sc_K, &h->sc_cam, &h->sc_frame, &h->sc_pt, &h->sc_uv, &h->sc_partial, &h->sc_out })
         dev_free(*b);
     for (auto& e : h->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : h->chol_ev) hipEventDestroy(e);
-    if (h->host_back) hipHostFree(h->host_back);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    if (h->ev_jac) hipEventDestroy(h->ev_jac);
+    if (h->att[1].stream) hipStreamDestroy(h->att[1].stream);
+    if (h->own_stream && h->main_stream) hipStreamDestroy(h->main_stream);
     delete h;
 }
 
@@ -195,9 +230,10 @@ int srk_ba_set_stream(srk_ba* h, void* hip_stream)
 {
     if (!h) return SRK_E_ARGS;
     hipSetDevice(h->device);
+    select_attempt(h, 0);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
-    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    h->stream = h->main_stream = h->att[0].stream = reinterpret_cast<hipStream_t>(hip_stream);
     h->own_stream = false;
     return SRK_OK;
 }
@@ -366,10 +402,10 @@ static int make_plan(srk_ba* h, SrkChunkPlan& pl, int64_t ld, int64_t sepw, int6
     std::vector<int64_t> sep_start((size_t)(P - 1));
     int64_t pos = 0;
     auto alloc = [&](size_t bytes, bool zero) -> void* {
-        h->plan_bufs.emplace_back();
-        if (dev_alloc(h, h->plan_bufs.back(), bytes) != SRK_OK) return nullptr;
-        if (zero) hipMemsetAsync(h->plan_bufs.back().p, 0, bytes, h->stream);
-        return h->plan_bufs.back().p;
+        h->A->plan_bufs.emplace_back();
+        if (dev_alloc(h, h->A->plan_bufs.back(), bytes) != SRK_OK) return nullptr;
+        if (zero) hipMemsetAsync(h->A->plan_bufs.back().p, 0, bytes, h->stream);
+        return h->A->plan_bufs.back().p;
     };
     for (int c = 0; c < P; ++c) {
         int64_t nb = blocks / P + (c < blocks % P ? 1 : 0);
@@ -423,8 +459,8 @@ static int make_plan(srk_ba* h, SrkChunkPlan& pl, int64_t ld, int64_t sepw, int6
     HIPCHK(h, hipMemcpyAsync(pl.d_sep_env, sep_env.data(), (size_t)(8 * (lds / 128)), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     // the separator system, chunked again when that shortens its chain
-    h->plan_children.emplace_back(new SrkChunkPlan());
-    SrkChunkPlan* child = h->plan_children.back().get();
+    h->A->plan_children.emplace_back(new SrkChunkPlan());
+    SrkChunkPlan* child = h->A->plan_children.back().get();
     int rc = make_plan(h, *child, lds, sepw, sepw, pl.s_row_end, pl.s_col_begin);
     if (rc != SRK_OK) return rc;
     pl.child = child->P >= 2 ? child : nullptr;
@@ -435,12 +471,12 @@ static int make_plan(srk_ba* h, SrkChunkPlan& pl, int64_t ld, int64_t sepw, int6
 static int build_chunk_plan(srk_ba* h)
 {
     const SrkDims& d = h->d;
-    SrkChunkPlan& pl = h->plan;
+    SrkChunkPlan& pl = h->A->plan;
     pl.P = 0;
     pl.child = nullptr;
-    for (DevBuf& b : h->plan_bufs) dev_free(b);
-    h->plan_bufs.clear();
-    h->plan_children.clear();
+    for (DevBuf& b : h->A->plan_bufs) dev_free(b);
+    h->A->plan_bufs.clear();
+    h->A->plan_children.clear();
     if (!h->use_envelope || !h->use_chunks) return SRK_OK;
     int64_t maxdist = 0;
     for (int32_t j = 0; j < d.M; ++j) maxdist = std::max<int64_t>(maxdist, 10 * (int64_t)(j - h->min_cv[(size_t)j]) + 9);
@@ -503,9 +539,17 @@ static int build_envelope(srk_ba* h)
         HIPCHK(h, hipMemcpyAsync(h->band_off.p, bo.data(), (size_t)(8 * (d.ld + 1)), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream)); // bc / bo are locals
     }
-    HIPCHK(h, hipMemsetAsync(h->S.p, 0, (size_t)(8 * d.ld * d.ld), h->stream)); // everything outside the skyline stays 0
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return build_chunk_plan(h);
+    for (int sl = 0; sl < 2; ++sl) { // every allocated attempt slot: its own zeroed system and solver plan
+        select_attempt(h, 0);
+        if (!h->att[sl].allocated) continue;
+        HIPCHK(h, hipMemsetAsync(h->att[sl].S.p, 0, (size_t)(8 * d.ld * d.ld), h->stream)); // outside the skyline stays 0
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->A = &h->att[sl]; // plan buffers of slot sl, allocated and zeroed on the main stream
+        rc = build_chunk_plan(h);
+        h->A = &h->att[0];
+        if (rc != SRK_OK) return rc;
+    }
+    return SRK_OK;
 }
 
 extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
@@ -684,7 +728,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         int _r = dev_alloc(h, (buf), (size_t)(bytes)); \
         if (_r != SRK_OK) return _r;                   \
     } while (0)
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < 3; ++w) {
         ALLOC(h->pts[w], 24 * N);
         ALLOC(h->camR[w], 72 * (int64_t)M);
         ALLOC(h->camT[w], 24 * (int64_t)M);
@@ -704,15 +748,25 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->W, 8 * 30 * d.Os);
     ALLOC(h->Vg, 8 * 9 * d.Ns);
     ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
-    ALLOC(h->S, 8 * d.ld * d.ld);
-    ALLOC(h->rhs, 8 * d.ld);
-    ALLOC(h->wy, 8 * 2 * d.ld);
-    ALLOC(h->dc, 8 * d.ld);
-    ALLOC(h->acc, 8 * 3 * d.Ns + 64);
-    ALLOC(h->dx, 24 * N);
-    ALLOC(h->err_partial, 8 * std::max<int64_t>(1024, srk_error_partials_staged(d)));
-    ALLOC(h->err_out, 64);
-    ALLOC(h->info, 64);
+    select_attempt(h, 0);
+    // the second attempt slot exists only where it can be used: one rank (the exchanges of several ranks are issued in
+    // lock step, one attempt at a time)
+    const int n_slots = (h->speculate && !h->allreduce) ? 2 : 1;
+    for (int sl = 0; sl < 2; ++sl) {
+        srk_ba::Attempt& a = h->att[sl];
+        a.allocated = sl < n_slots;
+        if (!a.allocated) continue;
+        ALLOC(a.S, 8 * d.ld * d.ld);
+        ALLOC(a.rhs, 8 * d.ld);
+        ALLOC(a.wy, 8 * 2 * d.ld);
+        ALLOC(a.dc, 8 * d.ld);
+        ALLOC(a.acc, 8 * 3 * d.Ns + 64);
+        ALLOC(a.dx, 24 * N);
+        ALLOC(a.err_partial, 8 * std::max<int64_t>(1024, srk_error_partials_staged(d)));
+        ALLOC(a.err_out, 64);
+        ALLOC(a.info, 64);
+        ALLOC(a.dinv, 8 * 64 * d.ld);
+    }
     ALLOC(h->grp_first, 4 * grp_first.size());
     ALLOC(h->grp_count, 4 * grp_count.size());
     ALLOC(h->grp_nf, 4 * grp_nf.size());
@@ -721,7 +775,6 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->pt_mask, 4 * pt_mask.size());
     ALLOC(h->gen_list, 4 * gen_list.size());
     ALLOC(h->wg_jmin, 4 * wg_jmin.size());
-    ALLOC(h->dinv, 8 * 64 * d.ld);
 #undef ALLOC
     hipStream_t s = h->stream;
 #define H2D(buf, src, bytes)                                                                               \
@@ -751,9 +804,14 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->gen_list, gen_list.data(), 4 * gen_list.size());
     H2D(h->wg_jmin, wg_jmin.data(), 4 * wg_jmin.size());
 #undef H2D
-    HIPCHK(h, hipMemsetAsync(h->dc.p, 0, 8 * d.ld, s));
-    HIPCHK(h, hipMemsetAsync(h->dx.p, 0, 24 * N > 0 ? 24 * N : 8, s));
+    for (auto& a : h->att) {
+        if (!a.allocated) continue;
+        HIPCHK(h, hipMemsetAsync(a.dc.p, 0, 8 * d.ld, s));
+        HIPCHK(h, hipMemsetAsync(a.dx.p, 0, 24 * N > 0 ? 24 * N : 8, s));
+    }
     h->cur = 0;
+    h->att[0].trial = 1;
+    h->att[1].trial = 2;
     rc = compute_cam_packs(h, 0);
     if (rc != SRK_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(s)); // host staging vectors go out of scope
@@ -779,8 +837,12 @@ extern "C" int srk_ba_reset_scene(srk_ba* h)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
     HIPCHK(h, hipSetDevice(h->device));
+    select_attempt(h, 0);
     hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // a speculative attempt may still read the current scene
     h->cur = 0;
+    h->att[0].trial = 1;
+    h->att[1].trial = 2;
     if (h->d.N > 0) HIPCHK(h, hipMemcpyAsync(h->pts[0].p, h->pts0.p, 24 * h->d.N, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->camR[0].p, h->camR0.p, 72 * (int64_t)h->d.M, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->camT[0].p, h->camT0.p, 24 * (int64_t)h->d.M, hipMemcpyDeviceToDevice, s));
@@ -827,16 +889,16 @@ static int phase_error(srk_ba* h, int which, double* err_host, bool with_status 
     hipStream_t s = h->stream;
     int32_t np = srk_error_partials(d);
     srk_launch_error(s, d, P<double>(h->pts[which]), P<double>(h->cam[which]), P<int32_t>(h->obs_frame),
-                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->err_partial), np, P<double>(h->err_out),
+                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->A->err_partial), np, P<double>(h->A->err_out),
                      h->jac_fused ? P<int32_t>(h->wg_jmin) : nullptr);
     if (with_status)
-        srk_launch_status_pack(s, P<int>(h->info), reinterpret_cast<const int*>(reinterpret_cast<char*>(h->acc.p) + 8 * 3 * d.Ns),
-                               P<double>(h->err_out));
+        srk_launch_status_pack(s, P<int>(h->A->info), reinterpret_cast<const int*>(reinterpret_cast<char*>(h->A->acc.p) + 8 * 3 * d.Ns),
+                               P<double>(h->A->err_out));
     HIPCHK(h, hipGetLastError());
-    int rc = exchange(h, P<double>(h->err_out), with_status ? 3 : 1);
+    int rc = exchange(h, P<double>(h->A->err_out), with_status ? 3 : 1);
     if (rc != SRK_OK) return rc;
     if (err_host) {
-        HIPCHK(h, hipMemcpyAsync(err_host, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(err_host, h->A->err_out.p, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
     }
     return SRK_OK;
@@ -871,29 +933,29 @@ static int phase_schur(srk_ba* h, double c)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
-    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->S));
-    HIPCHK(h, hipMemsetAsync(h->rhs.p, 0, 8 * d.ld, s));
+    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->A->S));
+    HIPCHK(h, hipMemsetAsync(h->A->rhs.p, 0, 8 * d.ld, s));
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
-                             P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->S),
-                             P<double>(h->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
+                             P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S),
+                             P<double>(h->A->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
                              P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
-                     P<double>(h->S), P<double>(h->rhs), P<int32_t>(h->gen_list), h->n_generic);
+                     P<double>(h->A->S), P<double>(h->A->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());
     // G (frame blocks, damped) and the frame gradients are linear in this rank's landmarks as well, so they are added
     // before the exchange; the identity diagonal of fixed / padding variables comes from rank 0 alone
-    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->S), P<double>(h->rhs), h->rank == 0 ? 1.0 : 0.0);
+    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->A->S), P<double>(h->A->rhs), h->rank == 0 ? 1.0 : 0.0);
     HIPCHK(h, hipGetLastError());
     if (h->allreduce) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
         int rc;
         if ((rc = dev_alloc(h, h->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
         double* tail = P<double>(h->packed) + h->band_packed;
-        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->S), P<double>(h->packed), 0);
-        HIPCHK(h, hipMemcpyAsync(tail, h->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
+        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->packed), 0);
+        HIPCHK(h, hipMemcpyAsync(tail, h->A->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
         rc = exchange(h, P<double>(h->packed), h->band_packed + d.ld);
         if (rc != SRK_OK) return rc;
-        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->S), P<double>(h->packed), 1);
-        HIPCHK(h, hipMemcpyAsync(h->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
+        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->packed), 1);
+        HIPCHK(h, hipMemcpyAsync(h->A->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipGetLastError());
     }
     h->last_hessian_factor = c;
@@ -904,19 +966,19 @@ static int phase_schur(srk_ba* h, double c)
 static void launch_solve(srk_ba* h, SrkSolveProf* prof)
 {
     const SrkDims& d = h->d;
-    if (h->plan.P >= 2)
-        srk_chol_solve_chunked(h->stream, h->plan, d.ld, P<double>(h->S), P<double>(h->rhs), P<double>(h->dc),
-                               P<int64_t>(h->env_col), P<int>(h->info), prof);
+    if (h->A->plan.P >= 2)
+        srk_chol_solve_chunked(h->stream, h->A->plan, d.ld, P<double>(h->A->S), P<double>(h->A->rhs), P<double>(h->A->dc),
+                               P<int64_t>(h->env_col), P<int>(h->A->info), prof);
     else
-        srk_chol_solve(h->stream, d.ld, P<double>(h->S), P<double>(h->rhs), P<double>(h->wy), P<double>(h->dc),
-                       P<int>(h->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->dinv), prof);
+        srk_chol_solve(h->stream, d.ld, P<double>(h->A->S), P<double>(h->A->rhs), P<double>(h->A->wy), P<double>(h->A->dc),
+                       P<int>(h->A->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->A->dinv), prof);
 }
 
 static int phase_solve(srk_ba* h, bool profile)
 {
     const SrkDims& d = h->d;
-    HIPCHK(h, hipMemsetAsync(h->info.p, 0, 4, h->stream));
-    h->solve_prof = SrkSolveProf{};
+    HIPCHK(h, hipMemsetAsync(h->A->info.p, 0, 4, h->stream));
+    h->A->solve_prof = SrkSolveProf{};
     if (profile) {
         size_t need = (size_t)(2 * (2 * (d.ld / SRK_CHOL_NB) + 64)); // every level of a nested plan included
         while (h->chol_ev.size() < need) {
@@ -924,17 +986,17 @@ static int phase_solve(srk_ba* h, bool profile)
             HIPCHK(h, hipEventCreate(&e));
             h->chol_ev.push_back(e);
         }
-        h->solve_prof.ev = h->chol_ev.data();
-        h->solve_prof.cap = h->chol_ev.size();
+        h->A->solve_prof.ev = h->chol_ev.data();
+        h->A->solve_prof.cap = h->chol_ev.size();
     }
-    launch_solve(h, profile ? &h->solve_prof : nullptr);
+    launch_solve(h, profile ? &h->A->solve_prof : nullptr);
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
 
 static int read_info(srk_ba* h, int* info_host)
 {
-    HIPCHK(h, hipMemcpyAsync(info_host, h->info.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(info_host, h->A->info.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SRK_OK;
 }
@@ -943,19 +1005,19 @@ static int phase_backsub_apply(srk_ba* h, double c)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
-    int cur = h->cur, tr = 1 - h->cur;
-    HIPCHK(h, hipMemsetAsync(h->acc.p, 0, 8 * 3 * d.Ns + 64, s));
+    int cur = h->cur, tr = h->A->trial;
+    HIPCHK(h, hipMemsetAsync(h->A->acc.p, 0, 8 * 3 * d.Ns + 64, s));
     srk_launch_backsub(s, d, c, P<int32_t>(h->obs_frame), P<int32_t>(h->obs_pt), P<double>(h->W), P<double>(h->Vg),
-                       P<double>(h->dc), P<double>(h->acc), P<double>(h->pts[cur]), P<double>(h->pts[tr]),
-                       P<double>(h->dx));
+                       P<double>(h->A->dc), P<double>(h->A->acc), P<double>(h->pts[cur]), P<double>(h->pts[tr]),
+                       P<double>(h->A->dx));
     HIPCHK(h, hipGetLastError());
     return SRK_OK;
 }
 
 static int phase_cam_apply(srk_ba* h)
 {
-    int cur = h->cur, tr = 1 - h->cur;
-    srk_launch_cam_apply(h->stream, h->d.M, P<double>(h->camR[cur]), P<double>(h->camT[cur]), P<double>(h->dc),
+    int cur = h->cur, tr = h->A->trial;
+    srk_launch_cam_apply(h->stream, h->d.M, P<double>(h->camR[cur]), P<double>(h->camT[cur]), P<double>(h->A->dc),
                          P<double>(h->camR[tr]), P<double>(h->camT[tr]));
     HIPCHK(h, hipGetLastError());
     return compute_cam_packs(h, tr);
@@ -983,6 +1045,8 @@ int srk_ba_phase_schur(srk_ba* h, double c)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
     HIPCHK(h, hipSetDevice(h->device));
+    select_attempt(h, 0); // the staged calls always work on attempt slot 0
+    h->last_slot = 0;
     int rc = phase_schur(h, c);
     if (rc != SRK_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1014,7 +1078,7 @@ int srk_ba_phase_backsub(srk_ba* h, double c)
 int srk_ba_phase_accept(srk_ba* h)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
-    h->cur = 1 - h->cur;
+    std::swap(h->cur, h->att[0].trial); // slot 0's trial scene becomes current
     return SRK_OK;
 }
 
@@ -1051,10 +1115,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     if (h->seen_global < 0) {
         double seen_d = (double)d.O;
         if (h->allreduce) {
-            HIPCHK(h, hipMemcpyAsync(h->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
-            int rc = exchange(h, P<double>(h->err_out), 1);
+            HIPCHK(h, hipMemcpyAsync(h->A->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
+            int rc = exchange(h, P<double>(h->A->err_out), 1);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipMemcpyAsync(&seen_d, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(&seen_d, h->A->err_out.p, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
         }
         h->seen_global = (int64_t)seen_d;
@@ -1067,7 +1131,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     int rc = phase_error(h, h->cur, nullptr);
     if (rc != SRK_OK) return fail_device(rc);
     EVREC(1);
-    HIPCHK(h, hipMemcpyAsync(&err_initial, h->err_out.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(&err_initial, h->A->err_out.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     rep->ms_error += ev_ms(0, 1);
     rep->err_initial = rep->err_final = err_initial;
@@ -1080,6 +1144,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         done = true;
     }
     double err_value = err_initial;
+    bool spec_wanted = false, spec_drain = false;
     while (!done) {
         if (max_iterations > 0 && rep->iterations >= max_iterations) {
             rep->status = SRK_STATUS_MAX_ITERATIONS;
@@ -1094,37 +1159,84 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         rep->jacobian_launches += 2;
         bool jac_timed = false;
 
-        // try_decrease_targ_fun (:764-852): the backup is the untouched `cur` buffer set, the trial lives in 1-cur
+        HIPCHK(h, hipEventRecord(h->ev_jac, s));
+
+        // try_decrease_targ_fun (:764-852): the backup is the untouched `cur` buffer set, every attempt slot has a trial
+        // set of its own.  With two slots the NEXT damping factor (x10) is tried speculatively beside the current one on
+        // a second stream: the solve is a latency chain that leaves most of the chip idle, so the pair costs little more
+        // than one attempt, and a rejected first attempt finds its successor already done.  Attempts are still judged
+        // strictly in the reference's order; a speculative result that is not needed is dropped unseen.
         bool have_prev = false;
         double err_new_prev = 0, err_new = std::nan("");
         int decrease = 0; // 1 success, 2 hessian overflow, 3 converged
-        while (!decrease) {
-            rep->attempts += 1;
-            EVREC(2);
-            rc = phase_schur(h, hessian_factor);
-            if (rc != SRK_OK) return fail_device(rc);
-            EVREC(3);
-            rc = phase_solve(h, h->profile_level >= 2);
-            if (rc != SRK_OK) return fail_device(rc);
-            EVREC(4);
-            rc = phase_backsub_apply(h, hessian_factor);
-            if (rc != SRK_OK) return fail_device(rc);
-            EVREC(5);
-            rc = phase_cam_apply(h);
-            if (rc != SRK_OK) return fail_device(rc);
-            EVREC(6);
-            rc = phase_error(h, 1 - h->cur, nullptr, true);
-            if (rc != SRK_OK) return fail_device(rc);
-            EVREC(7);
+        int accepted_slot = 0;
+        // one attempt, enqueued on slot sl's stream without waiting for it
+        auto enqueue_attempt = [&](int sl, double c) -> int {
+            select_attempt(h, sl);
+            hipStream_t st = h->stream;
+            int r2 = SRK_OK;
+            if (sl == 1 && hipStreamWaitEvent(st, h->ev_jac, 0) != hipSuccess) r2 = SRK_E_DEVICE;
+            if (sl == 0) EVREC(2);
+            if (r2 == SRK_OK) r2 = phase_schur(h, c);
+            if (sl == 0) EVREC(3);
+            if (r2 == SRK_OK) r2 = phase_solve(h, h->profile_level >= 2);
+            if (sl == 0) EVREC(4);
+            if (r2 == SRK_OK) r2 = phase_backsub_apply(h, c);
+            if (sl == 0) EVREC(5);
+            if (r2 == SRK_OK) r2 = phase_cam_apply(h);
+            if (sl == 0) EVREC(6);
+            if (r2 == SRK_OK) r2 = phase_error(h, h->A->trial, nullptr, true);
+            if (sl == 0) EVREC(7);
             // one read-back per attempt into pinned host memory: {error, solver info, point-update info}
-            HIPCHK(h, hipMemcpyAsync(h->host_back, h->err_out.p, 24, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipStreamSynchronize(s));
-            struct { double err; int info; } back{ h->host_back[0], (int)h->host_back[1] };
-            const int info2 = (int)h->host_back[2];
+            if (r2 == SRK_OK && hipMemcpyAsync(h->A->host_back, h->A->err_out.p, 24, hipMemcpyDeviceToHost, st) != hipSuccess)
+                r2 = SRK_E_DEVICE;
+            if (r2 == SRK_OK && hipEventRecord(h->A->done, st) != hipSuccess) r2 = SRK_E_DEVICE;
+            select_attempt(h, 0);
+            return r2;
+        };
+        // wait for slot sl's attempt and judge it exactly as the reference judges the attempt with factor `hessian_factor`
+        auto judge_attempt = [&](int sl) -> int {
+            if (hipStreamSynchronize(h->att[sl].stream) != hipSuccess) return SRK_E_DEVICE;
+            const double* hb = h->att[sl].host_back;
+            struct { double err; int info; } back{ hb[0], (int)hb[1] };
+            const int info2 = (int)hb[2];
+            rep->attempts += 1;
+            rep->schur_launches += 2;
+            h->last_slot = sl;
             if (getenv("SRK_DEBUG"))
-                fprintf(stderr, "srk_ba[rank %d] iteration %lld attempt %lld: hessian_factor %.3g err %.17g -> %.17g, solver info %d, "
-                                "point-update info %d\n", h->rank, (long long)rep->iterations + 1, (long long)rep->attempts,
-                        hessian_factor, err_value, back.err, back.info, info2);
+                fprintf(stderr, "srk_ba[rank %d] iteration %lld attempt %lld (slot %d): hessian_factor %.3g err %.17g -> %.17g, "
+                                "solver info %d, point-update info %d\n", h->rank, (long long)rep->iterations + 1,
+                        (long long)rep->attempts, sl, hessian_factor, err_value, back.err, back.info, info2);
+            if (back.info != 0 || info2 != 0) { decrease = 2; return SRK_OK; } // solve failed (:807-808, :1912-1913, :1953-1954)
+            err_new = back.err;
+            if (err_new - err_value < 0) { decrease = 1; accepted_slot = sl; return SRK_OK; } // :816-819
+            // restore = drop the trial buffers (:823-826)
+            if (have_prev && allowed_err_change) { // :828-838
+                double change = err_new - err_new_prev;
+                if (std::fabs(change) < *allowed_err_change) { decrease = 3; return SRK_OK; }
+            }
+            hessian_factor *= 10; // :841
+            if (max_hessian_factor && hessian_factor > *max_hessian_factor) { decrease = 2; return SRK_OK; } // :843-847
+            err_new_prev = err_new;
+            have_prev = true;
+            return SRK_OK;
+        };
+        const bool can_speculate = h->speculate && !h->allreduce && h->att[1].allocated && h->profile_level == 0;
+        bool spec_in_flight = false;
+        while (!decrease) {
+            rc = enqueue_attempt(0, hessian_factor);
+            if (rc != SRK_OK) return fail_device(rc);
+            // speculate once this optimise call has seen a rejection (or from its second iteration on): the first
+            // iteration of a fresh scene is usually accepted at once
+            const bool speculate_now = can_speculate && (spec_wanted || rep->iterations >= 1) &&
+                                       !(max_hessian_factor && hessian_factor * 10 > *max_hessian_factor);
+            if (speculate_now) {
+                rc = enqueue_attempt(1, hessian_factor * 10);
+                if (rc != SRK_OK) return fail_device(rc);
+                spec_in_flight = true;
+            }
+            rc = judge_attempt(0);
+            if (rc != SRK_OK) return fail_device(rc);
             if (!jac_timed) {
                 rep->ms_jacobian += ev_ms(0, 1);
                 rep->ms_jacobian_kernel += ev_ms(12, 13);
@@ -1135,34 +1247,38 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->ms_backsub += ev_ms(4, 5);
             rep->ms_apply += ev_ms(5, 6);
             rep->ms_error += ev_ms(6, 7);
-            rep->schur_launches += 2;
             if (h->profile_level >= 2) {
-                for (size_t kb = 0; kb < h->solve_prof.n; ++kb) {
+                for (size_t kb = 0; kb < h->att[0].solve_prof.n; ++kb) {
                     float ms = 0;
                     if (hipEventElapsedTime(&ms, h->chol_ev[2 * kb], h->chol_ev[2 * kb + 1]) == hipSuccess)
                         rep->ms_solve_syrk += ms;
                 }
-                rep->solve_mfma_flops += h->solve_prof.flops;
+                rep->solve_mfma_flops += h->att[0].solve_prof.flops;
             }
-            if (back.info != 0 || info2 != 0) { decrease = 2; break; } // solve failed (:807-808, :1912-1913, :1953-1954)
-            err_new = back.err;
-            if (err_new - err_value < 0) { decrease = 1; break; } // :816-819
-            // restore = drop the trial buffers (:823-826)
-            if (have_prev && allowed_err_change) { // :828-838
-                double change = err_new - err_new_prev;
-                if (std::fabs(change) < *allowed_err_change) { decrease = 3; break; }
+            if (!decrease) spec_wanted = true; // a rejection: from now on pairs pay
+            if (!decrease && speculate_now) { // the successor was computed meanwhile, with exactly this factor
+                rc = judge_attempt(1);
+                if (rc != SRK_OK) return fail_device(rc);
+                spec_in_flight = false;
             }
-            hessian_factor *= 10; // :841
-            if (max_hessian_factor && hessian_factor > *max_hessian_factor) { decrease = 2; break; } // :843-847
-            err_new_prev = err_new;
-            have_prev = true;
+        }
+        if (spec_in_flight) {
+            // a speculative attempt nobody needs is still running: later work on the main stream (the next derivatives
+            // overwrite what it reads) must come after it; nothing on the host waits
+            HIPCHK(h, hipStreamWaitEvent(s, h->att[1].done, 0));
+            spec_in_flight = false;
+            spec_drain = true;
         }
         if (decrease != 1) { // :857-873
             rep->status = decrease == 2 ? SRK_STATUS_HESSIAN_OVERFLOW : SRK_STATUS_ERR_CONVERGED;
             result_true = false;
             break;
         }
-        h->cur = 1 - h->cur; // accept: the trial scene becomes current
+        { // accept: the winning slot's trial scene becomes current, the old current set becomes that slot's trial set
+            const int newcur = h->att[accepted_slot].trial;
+            h->att[accepted_slot].trial = h->cur;
+            h->cur = newcur;
+        }
         rep->iterations += 1;
         double change = err_new - err_value;
         rep->err_final = err_new;
@@ -1174,6 +1290,8 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         err_value = err_new;
         hessian_factor /= 10; // :889
     }
+    if (spec_drain) HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // leave no speculative work behind
+    select_attempt(h, 0);
     rep->hessian_factor = hessian_factor;
     rep->optimized = result_true ? 1 : 0;
     rep->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1240,10 +1358,10 @@ static int score_scene(srk_ba* h, double f0, int64_t N, const double* pts, int32
     srk_launch_error_score(s, O, P<double>(h->sc_pts), P<double>(h->sc_cam), P<int32_t>(h->sc_frame), P<int32_t>(h->sc_pt),
                            P<double>(h->sc_uv), z_tol, P<double>(h->sc_partial), np, P<double>(h->sc_out));
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->host_back, h->sc_out.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->A->host_back, h->sc_out.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    *err = h->host_back[0];
-    *count = (int64_t)h->host_back[1];
+    *err = h->A->host_back[0];
+    *count = (int64_t)h->A->host_back[1];
     return SRK_OK;
 }
 
@@ -1495,6 +1613,13 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
     HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipStreamSynchronize(h->att[1].stream));
+    // reduced camera system, rhs and corrections: those of the last attempt the LM loop judged (or of the staged calls)
+    struct SlotGuard {
+        srk_ba* h;
+        ~SlotGuard() { h->A = &h->att[0]; }
+    } guard{ h };
+    h->A = &h->att[h->last_slot];
     auto d2h = [&](void* dstp, const void* src, size_t bytes) -> int {
         if (bytes == 0) return SRK_OK;
         HIPCHK(h, hipMemcpy(dstp, src, bytes, hipMemcpyDeviceToHost));
@@ -1546,7 +1671,7 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
         int64_t n = 10 * (int64_t)d.M;
         std::vector<double> row((size_t)d.ld);
         for (int64_t r = 0; r < n; ++r) {
-            if ((rc = d2h(row.data(), P<double>(h->S) + r * d.ld, (size_t)(8 * n))) != SRK_OK) return rc;
+            if ((rc = d2h(row.data(), P<double>(h->A->S) + r * d.ld, (size_t)(8 * n))) != SRK_OK) return rc;
             for (int64_t c = 0; c <= r; ++c) {
                 dst[r * n + c] = row[(size_t)c];
                 dst[c * n + r] = row[(size_t)c]; // lower triangle is authoritative
@@ -1554,12 +1679,12 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
         }
         return SRK_OK;
     }
-    case SRK_BUF_RCS_RHS: return d2h(dst, h->rhs.p, (size_t)(80 * (int64_t)d.M));
+    case SRK_BUF_RCS_RHS: return d2h(dst, h->A->rhs.p, (size_t)(80 * (int64_t)d.M));
     case SRK_BUF_CORRECTIONS: {
         std::vector<double> tmp((size_t)(3 * d.N));
-        if ((rc = d2h(tmp.data(), h->dx.p, (size_t)(24 * d.N))) != SRK_OK) return rc;
+        if ((rc = d2h(tmp.data(), h->A->dx.p, (size_t)(24 * d.N))) != SRK_OK) return rc;
         for (int64_t i = 0; i < d.N; ++i) std::memcpy(dst + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
-        return d2h(dst + 3 * d.N, h->dc.p, (size_t)(80 * (int64_t)d.M));
+        return d2h(dst + 3 * d.N, h->A->dc.p, (size_t)(80 * (int64_t)d.M));
     }
     case SRK_BUF_POINTS: {
         std::vector<double> tmp((size_t)(3 * d.N));
@@ -1644,7 +1769,7 @@ int srk_ba_set_rcs_mode(srk_ba* h, int use_envelope)
     return SRK_OK;
 }
 
-int srk_ba_rcs_chunks(srk_ba* h) { return (h && h->have_scene) ? h->plan.P : 0; }
+int srk_ba_rcs_chunks(srk_ba* h) { return (h && h->have_scene) ? h->A->plan.P : 0; }
 
 // fraction of the lower triangle inside the skyline (1.0 = dense)
 double srk_ba_rcs_fill(srk_ba* h)
@@ -1662,6 +1787,13 @@ double srk_ba_solve_mfma_flops(srk_ba* h)
     dry.dry = true; // walks the launch sequence of the current mode without launching anything
     launch_solve(h, &dry);
     return dry.flops;
+}
+
+int srk_ba_set_speculation(srk_ba* h, int on)
+{
+    if (!h || (on != 0 && on != 1)) return SRK_E_ARGS;
+    h->speculate = on != 0; // takes effect at the next upload (the second attempt slot is allocated there)
+    return SRK_OK;
 }
 
 int srk_ba_set_schur_precision(srk_ba* h, int fp32)

@@ -279,7 +279,11 @@ def test_compute_inplace_matches_oracle(orc, gpu, name, allowed, max_it):
 def test_compute_inplace_iteration_cap_and_report(orc, gpu):
     spec = SCENES["ragged_wave"]
     sc = sa.generate_scene(spec)
-    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, max_iterations=2)
+    gpu.set_profile(1)  # phase events fill report.ms_* (and serialise the attempts)
+    try:
+        rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, max_iterations=2)
+    finally:
+        gpu.set_profile(0)
     assert not ok and rc_o == 1
     assert sa.status_string(rep.status) == "max iterations" == orc.status_string(rep_o.status)
     assert rep.iterations == 2 == rep_o.iterations and rep.attempts == rep_o.attempts
@@ -578,7 +582,7 @@ def test_nested_plan_counts_its_mfma_flops(gpu):
             assert r.ms_solve_syrk > 0
             flops[mode] = gpu.solve_mfma_flops()
     finally:
-        gpu.set_profile(1)
+        gpu.set_profile(0)
         gpu.set_rcs_mode(2)
     assert gpu.rcs_chunks() >= 2
     assert flops[0] > flops[1] > 0
@@ -692,3 +696,36 @@ def test_fp32_schur_run_sums_stay_close_to_fp64(orc, gpu, name):
     assert rel_err(c32, c64) < 2e-3
     assert (it32, at32) == (it64, at64)
     assert e32 == pytest.approx(e64, rel=1e-4)
+
+
+# ------------------------------------------------------------------ speculative attempts
+
+@pytest.mark.parametrize("name", ["ragged_wave", "pixel_noise", "ragged_20"])
+def test_speculative_attempts_follow_the_sequential_loop(orc, name):
+    """Two attempt slots (the next damping factor runs beside the current one) against one slot: the same accept /
+    reject sequence, status, errors and scene -- and both equal to the oracle's loop."""
+    if name in SCENES:
+        spec, sc = SCENES[name], sa.generate_scene(SCENES[name])
+    else:
+        spec, frac = RAGGED[name]
+        sc = sa.drop_observations(sa.generate_scene(spec), frac, seed=7)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(1e-9)
+    out = {}
+    for spec_on in (True, False):
+        h = sa.BundleAdjustmentKanatani(0)
+        try:
+            h.set_speculation(spec_on)
+            s2 = sc.copy()
+            ok = h.ComputeInplace(spec.f0, s2, crit, 12)
+            r = h.report
+            out[spec_on] = (ok, r.iterations, r.attempts, r.status, r.err_final, r.hessian_factor, s2)
+        finally:
+            h.close()
+    a, b = out[True], out[False]
+    assert a[:4] == b[:4] and a[1] >= 3 and a[2] > a[1]   # several iterations, some of them with rejected attempts
+    assert a[4] == pytest.approx(b[4], rel=1e-9) and a[5] == pytest.approx(b[5])
+    assert np.abs(a[6].points - b[6].points).max() < 1e-8 and np.abs(a[6].cam_T - b[6].cam_T).max() < 1e-8
+    so = _orc_scene(orc, sc)
+    rc_o, rep_o = orc.compute_inplace(spec.f0, so, 1e-9, None, 12)
+    assert (a[1], a[2]) == (rep_o.iterations, rep_o.attempts) and a[0] == (rc_o == 0)
