@@ -1145,6 +1145,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     }
     double err_value = err_initial;
     bool spec_wanted = false, spec_drain = false;
+    int64_t prev_attempts = 0; // attempts the previous iteration needed
     while (!done) {
         if (max_iterations > 0 && rep->iterations >= max_iterations) {
             rep->status = SRK_STATUS_MAX_ITERATIONS;
@@ -1223,13 +1224,19 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         };
         const bool can_speculate = h->speculate && !h->allreduce && h->att[1].allocated && h->profile_level == 0;
         bool spec_in_flight = false;
+        int round = 0;
+        const int64_t attempts_before = rep->attempts;
         while (!decrease) {
             rc = enqueue_attempt(0, hessian_factor);
             if (rc != SRK_OK) return fail_device(rc);
             // speculate once this optimise call has seen a rejection (or from its second iteration on): the first
             // iteration of a fresh scene is usually accepted at once
-            const bool speculate_now = can_speculate && (spec_wanted || rep->iterations >= 1) &&
+            // -- and after a rejected pair the third attempt usually is the last one: it runs alone unless the previous
+            // iteration needed four or more (then the damping factor has a long way to climb and pairs pay again)
+            const bool pair_pays = round == 0 ? (spec_wanted || rep->iterations >= 1) : (round >= 2 || prev_attempts >= 4);
+            const bool speculate_now = can_speculate && pair_pays &&
                                        !(max_hessian_factor && hessian_factor * 10 > *max_hessian_factor);
+            ++round;
             if (speculate_now) {
                 rc = enqueue_attempt(1, hessian_factor * 10);
                 if (rc != SRK_OK) return fail_device(rc);
@@ -1262,6 +1269,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
                 spec_in_flight = false;
             }
         }
+        prev_attempts = rep->attempts - attempts_before;
         if (spec_in_flight) {
             // a speculative attempt nobody needs is still running: later work on the main stream (the next derivatives
             // overwrite what it reads) must come after it; nothing on the host waits
