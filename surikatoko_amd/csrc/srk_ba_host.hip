@@ -108,6 +108,13 @@ struct srk_ba {
         }                                                                                            \
     } while (0)
 
+// SRK_DEBUG=1: plan and per-attempt traces on stderr
+static bool srk_debug()
+{
+    static const bool on = getenv("SRK_DEBUG") != nullptr;
+    return on;
+}
+
 static int dev_alloc(srk_ba* h, DevBuf& b, size_t bytes)
 {
     if (bytes == 0) bytes = 8;
@@ -394,7 +401,7 @@ static int make_plan(srk_ba* h, SrkChunkPlan& pl, int64_t ld, int64_t sepw, int6
     if (P < 2) return SRK_OK;
     const int64_t interior = ld - sepw * (P - 1);
     const int64_t blocks = interior / unit; // ld, sepw are multiples of unit
-    if (getenv("SRK_DEBUG"))
+    if (srk_debug())
         fprintf(stderr, "srk_ba chunk plan: system %lld -> %d chunks of <= %lld + %d separators of %lld\n", (long long)ld, P,
                 (long long)(((blocks + P - 1) / P) * unit), P - 1, (long long)sepw);
     pl.sepw = sepw;
@@ -1061,7 +1068,7 @@ int srk_ba_phase_solve(srk_ba* h)
     int info = 0;
     rc = read_info(h, &info);
     if (rc != SRK_OK) return rc;
-    if (info && getenv("SRK_DEBUG")) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution)\n", info);
+    if (info && srk_debug()) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution)\n", info);
     return info ? 1 : 0;
 }
 int srk_ba_phase_backsub(srk_ba* h, double c)
@@ -1204,7 +1211,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->attempts += 1;
             rep->schur_launches += 2;
             h->last_slot = sl;
-            if (getenv("SRK_DEBUG"))
+            if (srk_debug())
                 fprintf(stderr, "srk_ba[rank %d] iteration %lld attempt %lld (slot %d): hessian_factor %.3g err %.17g -> %.17g, "
                                 "solver info %d, point-update info %d\n", h->rank, (long long)rep->iterations + 1,
                         (long long)rep->attempts, sl, hessian_factor, err_value, back.err, back.info, info2);
