@@ -218,10 +218,11 @@ int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
 double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current mode / plan) */
 
-/* Speculative attempts (default on; takes effect at the next upload): with one rank and the instrumentation off
+/* Speculative attempts (default on; takes effect at the next upload): with the instrumentation off
  * (srk_ba_set_profile 0, the default) the LM loop runs the next damping factor on a second stream beside the current
  * one and judges the attempts in the reference's order, so results are those of the sequential loop; costs a second
- * reduced camera system in memory.  0 = strictly one attempt at a time. */
+ * reduced camera system in memory.  With several ranks every rank takes the same decisions, so the exchanges of the
+ * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time. */
 int srk_ba_set_speculation(srk_ba*, int on);
 
 /* Opt-in mixed precision for the reduced camera system (the reference's suriko_scalar_type_string = f32 switch,

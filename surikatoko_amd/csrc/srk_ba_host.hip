@@ -57,7 +57,7 @@ struct srk_ba {
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
     std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
-    DevBuf env_col, env_off, packed, band_col, band_off;
+    DevBuf env_col, env_off, band_col, band_off;
     int64_t env_packed = 0, band_packed = 0; // doubles inside the factorisation skyline / the pre-factorisation band
     bool use_envelope = true;
     // chunked solve of a banded system (srk_chol.hip): plan + its buffers
@@ -66,7 +66,7 @@ struct srk_ba {
     // corrections, the trial scene, the status words, and the stream it runs on.  Two slots let the loop run the next
     // damping factor speculatively beside the current one (the solve is a latency chain that leaves the chip idle).
     struct Attempt {
-        DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv;
+        DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv, packed;
         SrkChunkPlan plan;
         std::vector<DevBuf> plan_bufs;
         std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
@@ -199,10 +199,10 @@ void srk_ba_destroy(srk_ba* h)
                       &h->camT[2], &h->K, &h->cam[0], &h->cam[1], &h->cam[2], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
-                      &h->gen_list, &h->env_col, &h->env_off, &h->packed, &h->wg_jmin, &h->band_col, &h->band_off };
+                      &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
-        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv }) dev_free(*b);
+        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
@@ -756,9 +756,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->Vg, 8 * 9 * d.Ns);
     ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
     select_attempt(h, 0);
-    // the second attempt slot exists only where it can be used: one rank (the exchanges of several ranks are issued in
-    // lock step, one attempt at a time)
-    const int n_slots = (h->speculate && !h->allreduce) ? 2 : 1;
+    const int n_slots = h->speculate ? 2 : 1;
     for (int sl = 0; sl < 2; ++sl) {
         srk_ba::Attempt& a = h->att[sl];
         a.allocated = sl < n_slots;
@@ -955,13 +953,13 @@ static int phase_schur(srk_ba* h, double c)
     HIPCHK(h, hipGetLastError());
     if (h->allreduce) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
         int rc;
-        if ((rc = dev_alloc(h, h->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
-        double* tail = P<double>(h->packed) + h->band_packed;
-        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->packed), 0);
+        if ((rc = dev_alloc(h, h->A->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
+        double* tail = P<double>(h->A->packed) + h->band_packed;
+        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->A->packed), 0);
         HIPCHK(h, hipMemcpyAsync(tail, h->A->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
-        rc = exchange(h, P<double>(h->packed), h->band_packed + d.ld);
+        rc = exchange(h, P<double>(h->A->packed), h->band_packed + d.ld);
         if (rc != SRK_OK) return rc;
-        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->packed), 1);
+        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->A->packed), 1);
         HIPCHK(h, hipMemcpyAsync(h->A->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipGetLastError());
     }
@@ -1229,7 +1227,9 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             have_prev = true;
             return SRK_OK;
         };
-        const bool can_speculate = h->speculate && !h->allreduce && h->att[1].allocated && h->profile_level == 0;
+        // several ranks: every rank takes the same decisions, so the exchanges of the two slots (each on its own packed
+        // buffer) are issued in the same order everywhere; slot 0's solve then overlaps slot 1's Schur sum and exchange
+        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0;
         bool spec_in_flight = false;
         int round = 0;
         const int64_t attempts_before = rep->attempts;
