@@ -316,7 +316,9 @@ def main():
                                    "uploaded state",
                        "parallelism": f"landmark shards x{world}" if world > 1 else "single GPU",
                        "points_per_rank": shard.N, "obs_per_rank": shard.O, "rcs_dim": 10 * M - 7,
-                       "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks},
+                       "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks,
+                       "lm_attempts": "two attempt slots: the next damping factor runs beside the current one and is "
+                                      "judged in the reference's order (srk_ba_set_speculation)"},
             "iterations_done": iterations,
             "attempts_per_iteration": attempts_timed / max(iterations, 1),
             "first_iteration": first_iteration,
