@@ -1176,8 +1176,9 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         double err_new_prev = 0, err_new = std::nan("");
         int decrease = 0; // 1 success, 2 hessian overflow, 3 converged
         int accepted_slot = 0;
-        // one attempt, enqueued on slot sl's stream without waiting for it
-        auto enqueue_attempt = [&](int sl, double c) -> int {
+        // one attempt, enqueued on slot sl's stream without waiting for it, in two parts so that a pair can put both
+        // Schur sums (which fill the chip one after the other) in front of both solves
+        auto enqueue_schur = [&](int sl, double c) -> int {
             select_attempt(h, sl);
             hipStream_t st = h->stream;
             int r2 = SRK_OK;
@@ -1185,7 +1186,13 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             if (sl == 0) EVREC(2);
             if (r2 == SRK_OK) r2 = phase_schur(h, c);
             if (sl == 0) EVREC(3);
-            if (r2 == SRK_OK) r2 = phase_solve(h, h->profile_level >= 2);
+            select_attempt(h, 0);
+            return r2;
+        };
+        auto enqueue_rest = [&](int sl, double c) -> int {
+            select_attempt(h, sl);
+            hipStream_t st = h->stream;
+            int r2 = phase_solve(h, h->profile_level >= 2);
             if (sl == 0) EVREC(4);
             if (r2 == SRK_OK) r2 = phase_backsub_apply(h, c);
             if (sl == 0) EVREC(5);
@@ -1234,21 +1241,28 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         int round = 0;
         const int64_t attempts_before = rep->attempts;
         while (!decrease) {
-            rc = enqueue_attempt(0, hessian_factor);
-            if (rc != SRK_OK) return fail_device(rc);
             // speculate once this optimise call has seen a rejection (or from its second iteration on): the first
-            // iteration of a fresh scene is usually accepted at once
-            // -- and after a rejected pair the third attempt usually is the last one: it runs alone unless the previous
-            // iteration needed four or more (then the damping factor has a long way to climb and pairs pay again)
+            // iteration of a fresh scene is usually accepted at once -- and after a rejected pair the third attempt
+            // usually is the last one: it runs alone unless the previous iteration needed four or more (then the damping
+            // factor has a long way to climb and pairs pay again)
             const bool pair_pays = round == 0 ? (spec_wanted || rep->iterations >= 1) : (round >= 2 || prev_attempts >= 4);
             const bool speculate_now = can_speculate && pair_pays &&
                                        !(max_hessian_factor && hessian_factor * 10 > *max_hessian_factor);
             ++round;
-            if (speculate_now) {
-                rc = enqueue_attempt(1, hessian_factor * 10);
-                if (rc != SRK_OK) return fail_device(rc);
-                spec_in_flight = true;
+            // one rank: both Schur sums first (the second would otherwise wait behind ~0.6 ms of launch calls), then both
+            // solves.  Several ranks: a Schur phase ends in a blocking exchange, so slot 0's solve is enqueued before it
+            // and runs under slot 1's Schur sum and exchange.
+            rc = enqueue_schur(0, hessian_factor);
+            if (h->allreduce) {
+                if (rc == SRK_OK) rc = enqueue_rest(0, hessian_factor);
+                if (rc == SRK_OK && speculate_now) rc = enqueue_schur(1, hessian_factor * 10);
+            } else {
+                if (rc == SRK_OK && speculate_now) rc = enqueue_schur(1, hessian_factor * 10);
+                if (rc == SRK_OK) rc = enqueue_rest(0, hessian_factor);
             }
+            if (rc == SRK_OK && speculate_now) rc = enqueue_rest(1, hessian_factor * 10);
+            if (rc != SRK_OK) return fail_device(rc);
+            if (speculate_now) spec_in_flight = true;
             rc = judge_attempt(0);
             if (rc != SRK_OK) return fail_device(rc);
             if (!jac_timed) {
