@@ -1166,6 +1166,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         bool jac_timed = false;
 
         HIPCHK(h, hipEventRecord(h->ev_jac, s));
+        const auto t_iter = std::chrono::steady_clock::now(); // SRK_DEBUG trace only
 
         // try_decrease_targ_fun (:764-852): the backup is the untouched `cur` buffer set, every attempt slot has a trial
         // set of its own.  With two slots the NEXT damping factor (x10) is tried speculatively beside the current one on
@@ -1217,9 +1218,11 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             rep->schur_launches += 2;
             h->last_slot = sl;
             if (srk_debug())
-                fprintf(stderr, "srk_ba[rank %d] iteration %lld attempt %lld (slot %d): hessian_factor %.3g err %.17g -> %.17g, "
-                                "solver info %d, point-update info %d\n", h->rank, (long long)rep->iterations + 1,
-                        (long long)rep->attempts, sl, hessian_factor, err_value, back.err, back.info, info2);
+                fprintf(stderr, "srk_ba[rank %d] iteration %lld attempt %lld (slot %d, +%.3f ms): hessian_factor %.3g err %.17g -> "
+                                "%.17g, solver info %d, point-update info %d\n", h->rank, (long long)rep->iterations + 1,
+                        (long long)rep->attempts, sl,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_iter).count(),
+                        hessian_factor, err_value, back.err, back.info, info2);
             if (back.info != 0 || info2 != 0) { decrease = 2; return SRK_OK; } // solve failed (:807-808, :1912-1913, :1953-1954)
             err_new = back.err;
             if (err_new - err_value < 0) { decrease = 1; accepted_slot = sl; return SRK_OK; } // :816-819
