@@ -1,5 +1,6 @@
 // srk_ba_host.hip -- host side of libsrk_ba.so: the C ABI of include/srk_ba.h, the gauge normalisation, the
-// device-resident Levenberg-Marquardt loop and the buffer management.
+// device-resident Levenberg-Marquardt loop (two attempt slots: the next damping factor runs speculatively beside the
+// current one), the nested-dissection plan of the reduced camera system and the buffer management.
 //
 // Mirrors whigg/surikatoko cpp_impl/suriko-engine/src/bundle-adj-kanatani.cpp:
 //   ComputeInplace :617-718, ComputeOnNormalizedWorld :720-893 (LM control), SceneNormalizer :123-333.

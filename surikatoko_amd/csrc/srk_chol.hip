@@ -17,6 +17,11 @@
 //                  remaining columns of the outer panel (MFMA as well).
 // The per-outer-panel row limit `row_end` lets the caller skip the structurally zero part of a banded / skyline
 // system (the envelope of a Cholesky factor equals the envelope of the matrix); dense = ld for every panel.
+//
+// Every factorisation kernel works on a BATCH of matrices (CholBatch, blockIdx.z = item): a banded system is cut into
+// chunks with separators between them (nested dissection, srk_chol_solve_chunked further down), the chunks of a level
+// advance in lock step through one launch sequence, and the separator system is chunked again.  A plain solve is a
+// batch of one.  The solver has no atomics and a fixed summation order (bit-reproducible).
 #include "srk_dev.hpp"
 
 #define NB 64
