@@ -1111,6 +1111,356 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
     }
 }
 
+// ------------------------------------------------------------------ K3m: the run's sum as an fp64 MFMA product
+// SQ counters of the register-tile kernels above (tools/schur_pmc.sh): LDS array 65 % busy, a quarter of that bank
+// conflicts, vector ALU 50 % -- every FMA operand is an LDS read (0.3-0.4 doubles per FMA).  But the sum over a run's
+// landmarks IS a matrix product: with the run's W_i stacked as rows k = (landmark, point coordinate) and Y likewise,
+//     sum_i W_i^T E_i^-1 W_i = Wl^T Yl,   Wl, Yl: (3 np) x (10 nf),
+// a (10 nf) x (10 nf) x (3 np) fp64 GEMM.  v_mfma_f64_16x16x4 has the vector pipe's peak (78.6 TFLOP/s) but reads
+// 2 operand doubles per 16 FMAs of a lane, so neither LDS nor instruction issue limits it.  12 waves own the <= 91
+// 16x16 tiles on and below the diagonal of the 13 x 13 tile grid (8 a wave); four helper waves stage W (round r + 2),
+// form Y = E^-1 W (round r + 1) and keep the global loads of round r + 3 in flight while round r is multiplied -- one
+// barrier a round of four landmarks = three K = 4 steps.  Rows of the round buffers are k, columns the frame
+// variables, row stride 208 doubles (= 16 mod 32: the four k rows an MFMA operand spans hit different banks).
+// The element of the lower BLOCK triangle that lies above the TILE diagonal (a 10x10 diagonal block cut by a tile
+// boundary) is taken from its mirror image: the sum is symmetric.
+#ifdef SRK_MM_STAMPS // development (tools/mm_stamps.sh): in-kernel clock stamps of one multiplier and one loader lane
+__device__ long long g_mm_stamps[2048][16];
+#define MM_STAMP(k) do { if (tid == 0 && blockIdx.x < 2048) g_mm_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
+#define MM_ACC(who, k, t0) do { if (tid == (who) && blockIdx.x < 2048) { long long t_ = wall_clock64(); g_mm_stamps[blockIdx.x][k] += t_ - (t0); (t0) = t_; } } while (0)
+extern "C" void srk_dbg_mm_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_stamps), sizeof(long long) * 32768); }
+#else
+#define MM_STAMP(k)
+#define MM_ACC(who, k, t0)
+#endif
+#define SRK_MM_THREADS 1024
+#define SRK_MM_CW 12    // multiplying waves
+#define SRK_MM_SLOTS 8  // tiles per multiplying wave
+#define SRK_MM_LDW 208  // row stride of the round buffers (doubles): 13 tiles of 16 columns
+typedef double srk_double4 __attribute__((ext_vector_type(4)));
+// the K = 4 steps of one round for a wave with NS tiles: operands of all tiles first, then the MFMAs (branch-free)
+template <int NS>
+__device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, const double* by,
+                                               const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int ksteps)
+{
+    static_assert(NS % 4 == 0, "tiles go four at a time");
+    for (int ks = 0; ks < ksteps; ++ks) {
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += 4) { // four tiles at a time: eight operand registers live, not 2 NS
+            double av[4], bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                av[s] = bw[ks * 4 * SRK_MM_LDW + ta[s0 + s]];
+                bv[s] = by[ks * 4 * SRK_MM_LDW + tb[s0 + s]];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc[s0 + s], 0, 0, 0);
+        }
+    }
+}
+__global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
+    SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
+    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
+    const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
+    const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
+    const int32_t* __restrict__ grp_frames)
+{
+    constexpr int PB = SRK_GRP_PB;             // landmarks of a round
+    constexpr int KR = 3 * PB;                 // k rows of a round
+    constexpr int LDW = SRK_MM_LDW;            // row stride (doubles)
+    constexpr int WB = KR * LDW;               // one buffer: W or Y of a round
+    constexpr int CAP = 5 * WB;                // W0 | W1 | W2 | Y0 | Y1; the flush uses all of it
+    constexpr int QMAX = PB * SRK_WS_NF;       // observations of a round
+    constexpr int NH = SRK_MM_THREADS - 64 * SRK_MM_CW; // helper lanes
+    constexpr int NW = SRK_MM_THREADS / 64;
+    static_assert(SRK_WS_NF * 10 <= LDW && KR % 4 == 0, "round buffers");
+    static_assert(SRK_MM_CW * SRK_MM_SLOTS >= 13 * 14 / 2, "tiles do not fit the multiplying waves");
+    static_assert((SRK_GRP_MAXPTS + PB - 1) / PB < 64, "a run's row_ptr entries do not fit a wave");
+    __shared__ __attribute__((aligned(16))) double sBuf[CAP];
+    __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
+    __shared__ double sRhs[SRK_WS_NF * 10];
+    __shared__ int32_t sF[SRK_WS_NF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef SRK_MM_STAMPS
+    if (tid == 64 * SRK_MM_CW && blockIdx.x < 2048) for (int k = 10; k < 16; ++k) g_mm_stamps[blockIdx.x][k] = 0;
+    if (tid == 0 && blockIdx.x < 2048) { g_mm_stamps[blockIdx.x][5] = g_mm_stamps[blockIdx.x][6] = g_mm_stamps[blockIdx.x][7] = 0; g_mm_stamps[blockIdx.x][8] = clock64(); }
+    long long tacc = 0;
+#endif
+    MM_STAMP(0);
+    const int64_t p0 = grp_first[blockIdx.x];
+    const int np = grp_count[blockIdx.x];
+    const int nfu = grp_nf[blockIdx.x];
+    const bool ragged = nfu < 0;
+    const int nf = ragged ? -nfu : nfu;
+    if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
+    if (tid < nf) sF[tid] = grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid];
+    if (tid < nf * 10) sRhs[tid] = 0.0;
+    const int R = (np + PB - 1) / PB;
+    const int nf10 = nf * 10;
+    const int64_t o0 = row_ptr[p0];
+    // LDS column of observation (staged landmark pl, frame slot a), W row k = 10 m + r:  (3 pl + m) LDW + 10 a + r
+    // rounds 0 and 1 are staged by the whole workgroup, their loads in flight together with the 3x3 blocks' below
+    {
+        const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
+        constexpr int NI = (2 * 30 * QMAX + SRK_MM_THREADS - 1) / SRK_MM_THREADS;
+        double v[NI];
+        int dst[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int e = tid + SRK_MM_THREADS * j;
+            const int rd = e / (30 * QMAX), rem = e - rd * (30 * QMAX);
+            const int k = rem / QMAX, q = rem - k * QMAX;
+            const int oa = rd ? o1 : 0, nq = rd ? o2 - o1 : o1;
+            dst[j] = -1;
+            v[j] = 0;
+            if (rd < 2 && q < nq) {
+                v[j] = W[(int64_t)k * d.Os + o0 + oa + q];
+                int pl, a;
+                if (ragged) { pl = obs_pt[o0 + oa + q] - (int)(p0 + rd * PB); a = (int)obs_slot[o0 + oa + q]; }
+                else { pl = q / nf; a = q - pl * nf; }
+                const int m = k / 10, rr = k - 10 * m;
+                dst[j] = rd * WB + (3 * pl + m) * LDW + 10 * a + rr;
+            }
+        }
+        if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
+            double Einv[9], g[3];
+            bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (dst[j] >= 0) sBuf[dst[j]] = v[j];
+    }
+    // flush: TR tile rows (16 TR rows of the sum, LDW columns) at a time go through the arena as a dense block, then
+    // leave as one wave per row of S, the lanes walking the row's 10 (a + 1) columns of the lower block triangle
+    constexpr int TR = CAP / (16 * LDW);
+    auto flush_stream = [&](int t0) { // rows 16 t0 .. 16 (t0 + TR) - 1
+        for (int rho = wv; rho < 16 * TR; rho += NW) {
+            const int Rr = 16 * t0 + rho;
+            if (Rr >= nf10) break;
+            const int a = Rr / 10;
+            const int64_t row = 10 * (int64_t)sF[a] + (Rr - 10 * a);
+            if (srk_is_fixed_var(row, d.comp)) continue;
+            const double* src = sBuf + rho * LDW;
+            double* dst = S + row * d.ld;
+            for (int cw = lane; cw < 10 * (a + 1); cw += 64) {
+                const int b = cw / 10, cc = cw - b * 10;
+                const int64_t col = 10 * (int64_t)sF[b] + cc;
+                if (srk_is_fixed_var(col, d.comp)) continue;
+#ifdef SRK_SCH_NOFLUSH
+                if (d.N >= 0) continue;
+#endif
+                atomicAdd(&dst[col], -src[cw]);
+            }
+        }
+    };
+    const int nt = (nf10 + 15) >> 4; // tile rows of the sum
+    __syncthreads(); // sE, sF, sRhs and W of rounds 0 and 1 are visible
+    MM_STAMP(1);
+    // two roles, two code paths, one barrier sequence (1 + R for the rounds, two per flush pass)
+    if (wv >= SRK_MM_CW) {
+        // ---- helpers: lane h of 256
+        const int h = tid - 64 * SRK_MM_CW;
+        __builtin_amdgcn_s_setprio(2); // their few instructions must not queue behind the MFMA streams
+        const int rel = (int)(row_ptr[p0 + (lane * PB < np ? lane * PB : np)] - o0); // lane r: first observation of round r
+        // staging: lane h = QMAX sm + sq moves the ten W rows k = 10 sm .. 10 sm + 9 (point coordinate sm) of observation
+        // sq of the round: ten loads coalesced over sq, ten consecutive doubles of one LDS row
+        static_assert(3 * QMAX <= NH, "staging lanes");
+        const int sm = h / QMAX, sq = h - sm * QMAX;
+        double pre[10];
+        int sdst, nq_pre = 0;
+        {
+            const int pl = sq / nf, a = sq - pl * nf; // uniform runs: landmark q / nf, slot q % nf
+            sdst = (3 * pl + sm) * LDW + 10 * a;
+        }
+        auto load_round = [&](int r) { // global loads of round r into `pre` (left in flight)
+            const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
+            nq_pre = sm < 3 ? rb - ra : 0;
+            if (sq < nq_pre) {
+                const double* src = W + (int64_t)(10 * sm) * d.Os + o0 + ra + sq;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) pre[i] = src[(int64_t)i * d.Os];
+                if (ragged)
+                    sdst = (3 * (obs_pt[o0 + ra + sq] - (int)(p0 + r * PB)) + sm) * LDW + 10 * (int)obs_slot[o0 + ra + sq];
+            }
+        };
+        auto stage_round = [&](double* bw) { // `pre` -> W in LDS
+            if (sq < nq_pre) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) bw[sdst + i] = pre[i];
+            }
+        };
+        // Y = E^-1 W: helper wave ypl forms the rows of staged landmark ypl, its lanes take the columns lane + 64 i, and
+        // keep the rhs term W^T (E^-1 g) of those columns (the PB waves' shares meet in sRhs at the end)
+        static_assert(NH == 64 * PB, "one helper wave per staged landmark");
+        constexpr int NC = (SRK_WS_NF * 10 + 63) / 64;
+        const int ypl = __builtin_amdgcn_readfirstlane(h >> 6);
+        double racc[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) racc[i] = 0;
+        uint32_t mask_pre = 0; // ragged runs: the frame slots this wave's landmark of the NEXT Y round sees
+        auto load_mask = [&](int r) { if (ragged && r * PB + ypl < np) mask_pre = pt_mask[p0 + r * PB + ypl]; };
+        auto y_round = [&](int r, double* bw, double* by) { // Y of round r from its staged W
+            const int pb = r * PB;
+            const int nb = np - pb < PB ? np - pb : PB;
+            if (ypl < nb) {
+                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]); // rows are 96 B: 16-byte aligned
+                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
+                double w[NC][3];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int col = lane + 64 * i;
+                    const double* wp = bw + 3 * ypl * LDW + col;
+                    const bool on = col < nf10 && !(ragged && !((mask_pre >> (col / 10)) & 1u)); // else: zero blocks
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) w[i][m] = on ? wp[m * LDW] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int col = lane + 64 * i;
+                    if (col >= nf10) continue;
+                    double* wp = bw + 3 * ypl * LDW + col;
+                    double* yp = by + 3 * ypl * LDW + col;
+                    const double w0 = w[i][0], w1 = w[i][1], w2 = w[i][2];
+                    if (ragged) { wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2; } // a missed frame's stale W becomes zero
+                    yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
+                    yp[LDW] = e23.y * w0 + e45.x * w1 + e45.y * w2;
+                    yp[2 * LDW] = e67.x * w0 + e67.y * w1 + e89.x * w2;
+                    racc[i] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
+                }
+            }
+            // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
+            if (nb < PB)
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = by[3 * nb * LDW + t] = 0;
+        };
+        load_mask(0);
+        y_round(0, sBuf, sBuf + 3 * WB);
+        load_mask(1);
+        if (R > 2) load_round(2);
+        __syncthreads(); // Y of round 0 is visible
+#ifdef SRK_MM_STAMPS
+        tacc = wall_clock64();
+#endif
+        int wi = 2; // W buffer of round r + 2
+        for (int r = 0; r < R; ++r) {
+            if (r + 2 < R) stage_round(sBuf + wi * WB);
+#ifdef SRK_MM_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            MM_ACC(64 * SRK_MM_CW, 10, tacc);
+            if (r + 1 < R) {
+                const int w1 = wi == 0 ? 2 : wi - 1; // W buffer of round r + 1
+                y_round(r + 1, sBuf + w1 * WB, sBuf + (3 + ((r + 1) & 1)) * WB);
+                load_mask(r + 2);
+            }
+#ifdef SRK_MM_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            MM_ACC(64 * SRK_MM_CW, 13, tacc);
+            if (r + 3 < R) load_round(r + 3);
+            MM_ACC(64 * SRK_MM_CW, 11, tacc);
+            wi = wi == 2 ? 0 : wi + 1;
+            __syncthreads(); // the products of round r; W of round r + 2 and Y of round r + 1 are visible
+            MM_ACC(64 * SRK_MM_CW, 12, tacc);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
+        for (int t0 = 0; t0 < nt; t0 += TR) {
+            __syncthreads();
+            __syncthreads();
+            flush_stream(t0);
+        }
+    } else {
+        // ---- multipliers: wave wv owns tiles u = wv + SRK_MM_CW s (row-major over (ti, tj <= ti)) of the nt x nt grid
+        const int n_tiles = nt * (nt + 1) / 2;
+        const int lr = lane & 15, lk = lane >> 4;
+        // tile coordinates are wave-uniform: kept in scalar registers (readfirstlane), the lane part of an operand's
+        // LDS address is one VGPR
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const int lbase = lk * LDW + lr;
+        int ta[SRK_MM_SLOTS], tb[SRK_MM_SLOTS];
+        int ns = 0; // this wave's tiles
+#pragma unroll
+        for (int s = 0; s < SRK_MM_SLOTS; ++s) {
+            const int u = wvu + SRK_MM_CW * s;
+            const bool on = u < n_tiles;
+            const int uu = on ? u : 0;
+            int ti = (int)((sqrtf(8.0f * (float)uu + 1.0f) - 1.0f) * 0.5f);
+            while ((ti + 1) * (ti + 2) / 2 <= uu) ++ti;
+            while (ti * (ti + 1) / 2 > uu) --ti;
+            ta[s] = __builtin_amdgcn_readfirstlane(16 * ti);
+            tb[s] = __builtin_amdgcn_readfirstlane(16 * (uu - ti * (ti + 1) / 2));
+            ns += on ? 1 : 0;
+        }
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        srk_double4 acc[SRK_MM_SLOTS];
+#pragma unroll
+        for (int s = 0; s < SRK_MM_SLOTS; ++s) acc[s] = (srk_double4){ 0, 0, 0, 0 };
+        __syncthreads();
+        MM_STAMP(2);
+#ifdef SRK_MM_STAMPS
+        tacc = wall_clock64();
+#endif
+        int wi = 0; // W buffer of round r
+        for (int r = 0; r < R; ++r) {
+            const double* bw = sBuf + wi * WB;
+            const double* by = sBuf + (3 + (r & 1)) * WB;
+            wi = wi == 2 ? 0 : wi + 1;
+            const int nb = np - r * PB < PB ? np - r * PB : PB;
+            const int ksteps = (3 * nb + 3) >> 2;
+#ifdef SRK_SCH_NOACC
+            if (d.N < 0)
+#endif
+            schur_mm_steps<SRK_MM_SLOTS>(acc, bw + lbase, by + lbase, ta, tb, ksteps); // idle slots multiply tile (0, 0)
+            MM_ACC(0, 6, tacc);
+            __syncthreads();
+            MM_ACC(0, 7, tacc);
+        }
+        MM_STAMP(3);
+        // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg.  A tile just below the
+        // diagonal also supplies the mirror images the diagonal blocks it cuts need above the tile diagonal.
+#pragma nounroll
+        for (int t0 = 0; t0 < nt; t0 += TR) {
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SRK_MM_SLOTS; ++s) {
+                if (s >= ns) continue;
+                const int ti = ta[s] >> 4, tj = tb[s] >> 4; // wave-uniform
+                if (ti >= t0 && ti < t0 + TR) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) sBuf[(ta[s] - 16 * t0 + lk + 4 * reg) * LDW + tb[s] + lr] = acc[s][reg];
+                }
+                if (ti == tj + 1 && tj >= t0 && tj < t0 + TR) {
+                    const int Cc = tb[s] + lr, aC = Cc / 10;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int Rr = ta[s] + lk + 4 * reg;
+                        if (Rr < 10 * (aC + 1)) sBuf[(Cc - 16 * t0) * LDW + Rr] = acc[s][reg]; // same diagonal block
+                    }
+                }
+            }
+            __syncthreads();
+            flush_stream(t0);
+        }
+    }
+    // rhs += sum F^T E^-1 g (the helpers' sRhs adds precede the flush's barriers; nf >= 1 means at least one pass)
+    if (tid < nf10) {
+        const int a = tid / 10, r = tid - a * 10;
+        const int64_t row = 10 * (int64_t)sF[a] + r;
+        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], sRhs[tid]);
+    }
+    MM_STAMP(4);
+#ifdef SRK_MM_STAMPS
+    if (tid == 0 && blockIdx.x < 2048) g_mm_stamps[blockIdx.x][9] = clock64() - g_mm_stamps[blockIdx.x][8];
+#endif
+}
+
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
@@ -1118,15 +1468,18 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               int fp32_accumulate)
 {
     if (n_groups <= 0) return;
-    // the loader-wave kernel pays when the multiply of a round is long enough to hide the staging: fp64 only (with the
-    // packed fp32 products a round is too short and the single-role kernel is faster).  SRK_SCHUR_NO_WS: development.
+    // runs over at most SRK_WS_NF frames go to the MFMA kernel, fp64 only (the opt-in fp32 accumulation keeps the packed
+    // FMA register-tile kernel).  SRK_SCHUR_NO_WS / SRK_SCHUR_VALU: development switches back to the register-tile kernels.
     static const bool env_no_ws = getenv("SRK_SCHUR_NO_WS") != nullptr;
+    static const bool env_valu = getenv("SRK_SCHUR_VALU") != nullptr; // development: the register-tile kernel k_schur_ws
     const bool no_ws = env_no_ws || fp32_accumulate;
     const int nf_skip = no_ws ? 0 : SRK_WS_NF;
 #define SRK_SCHUR_ARGS d, c, row_ptr, obs_pt, obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames
     const dim3 grid((unsigned)n_groups), block(SRK_GRP_THREADS);
-    if (!no_ws && n_wide + n_mid < n_groups) // runs over at most SRK_WS_NF frames: loader-wave kernel
-        hipLaunchKernelGGL(k_schur_ws<double>, grid, block, 0, s, SRK_SCHUR_ARGS);
+    if (!no_ws && n_wide + n_mid < n_groups) { // runs over at most SRK_WS_NF frames: the MFMA kernel
+        if (env_valu) hipLaunchKernelGGL(k_schur_ws<double>, grid, block, 0, s, SRK_SCHUR_ARGS);
+        else hipLaunchKernelGGL(k_schur_mm, grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS);
+    }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread
         if (fp32_accumulate) hipLaunchKernelGGL((k_schur_grouped<1, float>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
         else hipLaunchKernelGGL((k_schur_grouped<1, double>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
