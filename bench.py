@@ -244,7 +244,7 @@ def main():
         kernels = {
             "jacobian_phase": hbm(ab["jacobian"], per_it["ms_jacobian"], "k_jac_fused"),
             "jacobian_kernel": hbm(ab["jacobian"], per_it["ms_jacobian_kernel"], "k_jac_fused"),
-            "schur_phase": hbm(ab["schur"], per_attempt["ms_schur"], "k_schur_ws", "k_schur_grouped", "k_schur", "k_env_zero",
+            "schur_phase": hbm(ab["schur"], per_attempt["ms_schur"], "k_schur_mm", "k_schur_ws", "k_schur_grouped", "k_schur", "k_env_zero",
                                "k_assemble"),
             "backsub_phase": hbm(ab["backsub"], per_attempt["ms_backsub"], "k_backsub_obs", "k_point_update"),
             "error_phase": hbm(ab["error"], per_attempt["ms_error"], "k_error", "k_error_staged"),
@@ -276,18 +276,19 @@ def main():
             "note": "64-column panel kernels + backward substitution of the blocked Cholesky (+ gather / reduce / "
                     "scatter of the nested-dissection levels): a dependency chain of pivots, bound by per-pivot "
                     "latency, not by HBM or MFMA throughput"}
-        # k_schur_grouped is compute-bound (22 flop per algorithmic byte against a machine balance of ~10): price it
-        # against the fp64 peak as well.  Useful flops: every landmark's lower block triangle, nf (nf + 1) / 2 blocks of
-        # 100 entries, 3 multiply-adds each (the kernel runs them as vector FMAs; the fp64 VALU peak equals the MFMA one).
+        # The Schur sum is compute-bound (22 flop per algorithmic byte against a machine balance of ~10): price it against
+        # the fp64 MFMA peak.  Useful flops: every landmark's lower block triangle, nf (nf + 1) / 2 blocks of 100 entries,
+        # 3 multiply-adds each (k_schur_mm runs them as v_mfma_f64_16x16x4 over the 16x16 tiles of a run's lower triangle:
+        # 91 tiles for 20 frames = 11 % more than the useful entries).
         nf = np.diff(shard.row_ptr).astype(np.float64)
         schur_flops = float((nf * (nf + 1) / 2).sum() * 600.0)
         tfs = schur_flops / (per_attempt["ms_schur"] * 1e-3) / 1e12 if per_attempt["ms_schur"] > 0 else 0.0
         kernels["schur_kernel_fp64"] = {
             "bound": "mfma", "achieved": tfs, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tfs / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic("k_schur_ws", "k_schur_grouped", "k_schur"),
+            "frac": tfs / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic("k_schur_mm", "k_schur_ws", "k_schur_grouped", "k_schur"),
             "ms": per_attempt["ms_schur"], "algorithmic_flops": schur_flops, "algorithmic_bytes": ab["schur"],
-            "note": "fp64 FMA bound (vector ALUs; the fp64 vector peak is the same 78.6 TFLOP/s as the matrix path); the "
-                    "time is the Schur phase = this kernel + ~20 us of zeroing / assembly"}
+            "note": "fp64 MFMA (v_mfma_f64_16x16x4: a run's landmark sum as a (10 nf)^2 x (3 np) matrix product); the time "
+                    "is the Schur phase = this kernel + ~20 us of zeroing / assembly"}
         # dominant kernel = the single kernel (or, for the solve, kernel class) with the largest share of the step.  The
         # panel chain of the solve is larger in total but is ~24 latency-bound launches with no throughput roof.
         shares = {"jacobian_kernel": per_it["ms_jacobian_kernel"], "schur_kernel_fp64": per_it["ms_schur"],

@@ -1133,6 +1133,9 @@ extern "C" void srk_dbg_mm_stamps(long long* out) { (void)hipMemcpyFromSymbol(ou
 #define MM_STAMP(k)
 #define MM_ACC(who, k, t0)
 #endif
+// workgroup barrier that orders LDS only: __syncthreads() would also drain vmcnt, i.e. make the helpers wait for the
+// global loads they have just put in flight for a later round, and every flush pass wait for its atomics
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #define SRK_MM_THREADS 1024
 #define SRK_MM_CW 12    // multiplying waves
 #define SRK_MM_SLOTS 8  // tiles per multiplying wave
@@ -1180,7 +1183,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     __shared__ __attribute__((aligned(16))) double sBuf[CAP];
     __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
     __shared__ double sRhs[SRK_WS_NF * 10];
-    __shared__ int32_t sF[SRK_WS_NF];
+    __shared__ int32_t sVar[SRK_WS_NF * 10]; // row / column of S of the sum's row / column e; -1: a gauge-fixed variable
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef SRK_MM_STAMPS
     if (tid == 64 * SRK_MM_CW && blockIdx.x < 2048) for (int k = 10; k < 16; ++k) g_mm_stamps[blockIdx.x][k] = 0;
@@ -1194,8 +1197,11 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const bool ragged = nfu < 0;
     const int nf = ragged ? -nfu : nfu;
     if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
-    if (tid < nf) sF[tid] = grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid];
-    if (tid < nf * 10) sRhs[tid] = 0.0;
+    if (tid < nf * 10) {
+        sRhs[tid] = 0.0;
+        const int64_t var = 10 * (int64_t)grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid / 10] + tid % 10;
+        sVar[tid] = srk_is_fixed_var(var, d.comp) ? -1 : (int)var;
+    }
     const int R = (np + PB - 1) / PB;
     const int nf10 = nf * 10;
     const int64_t o0 = row_ptr[p0];
@@ -1243,15 +1249,14 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         for (int rho = wv; rho < 16 * TR; rho += NW) {
             const int Rr = 16 * t0 + rho;
             if (Rr >= nf10) break;
-            const int a = Rr / 10;
-            const int64_t row = 10 * (int64_t)sF[a] + (Rr - 10 * a);
-            if (srk_is_fixed_var(row, d.comp)) continue;
+            const int row = sVar[Rr];
+            if (row < 0) continue;
             const double* src = sBuf + rho * LDW;
-            double* dst = S + row * d.ld;
-            for (int cw = lane; cw < 10 * (a + 1); cw += 64) {
-                const int b = cw / 10, cc = cw - b * 10;
-                const int64_t col = 10 * (int64_t)sF[b] + cc;
-                if (srk_is_fixed_var(col, d.comp)) continue;
+            double* dst = S + (int64_t)row * d.ld;
+            const int w = 10 * (Rr / 10 + 1);
+            for (int cw = lane; cw < w; cw += 64) {
+                const int col = sVar[cw];
+                if (col < 0) continue;
 #ifdef SRK_SCH_NOFLUSH
                 if (d.N >= 0) continue;
 #endif
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         }
     };
     const int nt = (nf10 + 15) >> 4; // tile rows of the sum
-    __syncthreads(); // sE, sF, sRhs and W of rounds 0 and 1 are visible
+    __syncthreads(); // sE, sVar, sRhs and W of rounds 0 and 1 are visible
     MM_STAMP(1);
     // two roles, two code paths, one barrier sequence (1 + R for the rounds, two per flush pass)
     if (wv >= SRK_MM_CW) {
@@ -1342,7 +1347,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         y_round(0, sBuf, sBuf + 3 * WB);
         load_mask(1);
         if (R > 2) load_round(2);
-        __syncthreads(); // Y of round 0 is visible
+        lds_barrier(); // Y of round 0 is visible
 #ifdef SRK_MM_STAMPS
         tacc = wall_clock64();
 #endif
@@ -1365,15 +1370,15 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (r + 3 < R) load_round(r + 3);
             MM_ACC(64 * SRK_MM_CW, 11, tacc);
             wi = wi == 2 ? 0 : wi + 1;
-            __syncthreads(); // the products of round r; W of round r + 2 and Y of round r + 1 are visible
+            lds_barrier(); // the products of round r; W of round r + 2 and Y of round r + 1 are visible
             MM_ACC(64 * SRK_MM_CW, 12, tacc);
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i)
             if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
         for (int t0 = 0; t0 < nt; t0 += TR) {
-            __syncthreads();
-            __syncthreads();
+            lds_barrier();
+            lds_barrier();
             flush_stream(t0);
         }
     } else {
@@ -1402,7 +1407,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         srk_double4 acc[SRK_MM_SLOTS];
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) acc[s] = (srk_double4){ 0, 0, 0, 0 };
-        __syncthreads();
+        lds_barrier();
         MM_STAMP(2);
 #ifdef SRK_MM_STAMPS
         tacc = wall_clock64();
@@ -1419,7 +1424,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #endif
             schur_mm_steps<SRK_MM_SLOTS>(acc, bw + lbase, by + lbase, ta, tb, ksteps); // idle slots multiply tile (0, 0)
             MM_ACC(0, 6, tacc);
-            __syncthreads();
+            lds_barrier();
             MM_ACC(0, 7, tacc);
         }
         MM_STAMP(3);
@@ -1427,7 +1432,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         // diagonal also supplies the mirror images the diagonal blocks it cuts need above the tile diagonal.
 #pragma nounroll
         for (int t0 = 0; t0 < nt; t0 += TR) {
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int s = 0; s < SRK_MM_SLOTS; ++s) {
                 if (s >= ns) continue;
@@ -1445,16 +1450,12 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             flush_stream(t0);
         }
     }
     // rhs += sum F^T E^-1 g (the helpers' sRhs adds precede the flush's barriers; nf >= 1 means at least one pass)
-    if (tid < nf10) {
-        const int a = tid / 10, r = tid - a * 10;
-        const int64_t row = 10 * (int64_t)sF[a] + r;
-        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], sRhs[tid]);
-    }
+    if (tid < nf10 && sVar[tid] >= 0) atomicAdd(&rhs[sVar[tid]], sRhs[tid]);
     MM_STAMP(4);
 #ifdef SRK_MM_STAMPS
     if (tid == 0 && blockIdx.x < 2048) g_mm_stamps[blockIdx.x][9] = clock64() - g_mm_stamps[blockIdx.x][8];
@@ -1705,7 +1706,7 @@ __global__ __launch_bounds__(256) void k_error(SrkDims d, const double* __restri
     sum = wave_sum(sum);
     int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     if (lane == 0) red[wave] = sum;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
@@ -1728,7 +1729,7 @@ __global__ __launch_bounds__(256) void k_error_staged(SrkDims d, const double* _
             sCam[js][e] = cam[(int64_t)SRK_CAM_PACK * (jmin + js) + (e < 21 ? e : 47)];
         }
     }
-    __syncthreads();
+    lds_barrier();
     const int64_t o_first = (int64_t)blockIdx.x * SRK_JF_OBS;
     double sum = 0;
 #pragma unroll
@@ -1752,7 +1753,7 @@ __global__ __launch_bounds__(256) void k_error_staged(SrkDims d, const double* _
     sum = wave_sum(sum);
     int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     if (lane == 0) red[wave] = sum;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
@@ -1787,7 +1788,7 @@ __global__ __launch_bounds__(256) void k_error_score(int64_t O, const double* __
     cnt = wave_sum(cnt);
     int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     if (lane == 0) red[wave] = sum, red[4 + wave] = cnt;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
         partial[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
@@ -1802,10 +1803,10 @@ __global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __
     double s = 0;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
     red[threadIdx.x] = s;
-    __syncthreads();
+    lds_barrier();
     for (int w = 128; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
+        lds_barrier();
     }
     if (threadIdx.x == 0) out[0] = red[0];
 }
@@ -1994,7 +1995,7 @@ __global__ __launch_bounds__(256) void k_mvf_gram(int64_t P, const double* __res
             if (lane == 0) red[wave][e] = g;
             ++e;
         }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 78)
         partial[(int64_t)blockIdx.x * 78 + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
