@@ -3,11 +3,11 @@
 // Reference being accelerated (whigg/surikatoko, cpp_impl/suriko-engine/src/bundle-adj-kanatani.cpp):
 //   reprojection error                :410-490   -> k_error / k_error_final
 //   closed-form derivatives           :1140-1549 -> k_jac_points (point-major) + k_jac_frames (frame-major)
-//   reduced camera system (Schur)     :1771-1908 -> k_schur + k_assemble
+//   reduced camera system (Schur)     :1771-1908 -> k_schur_mm (fp64 MFMA) / k_schur_grouped / k_schur + k_assemble
 //   point back-substitution + apply   :1919-1960, :1997-2017 -> k_backsub_obs + k_point_update
 //   camera apply (Rodrigues)          :2021-2062, :59-92     -> k_cam_apply
-// All arithmetic is fp64 (reference Scalar = double).  These kernels are HBM-bound streaming passes over the
-// observation arrays: every global access is lane-contiguous (SoA blocks), per-landmark sums are wavefront
+// All arithmetic is fp64 (reference Scalar = double).  Except for the Schur sum (compute bound: a matrix product per
+// run of landmarks) these kernels are HBM-bound streaming passes over the observation arrays: every global access is lane-contiguous (SoA blocks), per-landmark sums are wavefront
 // segmented reductions, per-frame sums are register accumulators + wavefront reductions + one atomic per block.
 #include "srk_dev.hpp"
 
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
-    const int32_t* __restrict__ grp_frames, int nf_skip /* runs with at most this many frames belong to k_schur_ws */)
+    const int32_t* __restrict__ grp_frames, int nf_skip /* runs with at most this many frames belong to k_schur_mm / k_schur_ws */)
 {
     // one LDS arena: W | Y staging during the accumulation, then the staging buffer of the coalesced flush
     using L = SchurLayout<T>;

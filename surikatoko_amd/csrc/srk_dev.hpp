@@ -53,7 +53,7 @@ void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* 
 #define SRK_GRP_MAXNF_HOST 24   // must match SRK_GRP_MAXNF in srk_ba_kernels.hip
 #define SRK_GRP_MAXPTS_HOST 128 // landmarks per workgroup run
 #define SRK_GRP_NF1_HOST 21     // must match SRK_GRP_NF1
-#define SRK_WS_NF_HOST 20       // must match SRK_WS_NF (runs the loader-wave kernel takes)
+#define SRK_WS_NF_HOST 20       // must match SRK_WS_NF (runs the MFMA kernel k_schur_mm takes)
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
                               const uint8_t* obs_slot /* [O] slot of the observation's frame in its run's frame set */,
                               const uint32_t* pt_mask /* [N] slots a landmark sees */, const double* W, const double* Vg,
