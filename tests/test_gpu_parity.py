@@ -179,6 +179,25 @@ def test_phases_on_synthetic_scenes(orc, gpu, name, c):
     _check(out, sc.M, corr_tol=1e-7)
 
 
+MFMA_EDGES = {
+    # k_schur_mm sums a run as a (10 nf) x (10 nf) x (3 np) fp64 MFMA product over 16x16 tiles and rounds of four
+    # landmarks: frame counts whose 10 nf is / is not a multiple of 16, runs that are not a multiple of four landmarks
+    # long, groups split into several runs (> 128 landmarks), one- and two-frame runs
+    "nf16_10_tiles": sa.SceneSpec(n_frames=24, grid_nx=30, grid_ny=20, vis_window=16),   # 160 = 10 tiles exactly; runs of 64..68
+    "nf20_split_runs": sa.SceneSpec(n_frames=23, grid_nx=33, grid_ny=31, vis_window=20), # 200 -> 13 tiles; groups of 255 / 256
+    "nf13": sa.SceneSpec(n_frames=15, grid_nx=17, grid_ny=13, vis_window=13),            # 130 -> 9 tiles; runs of 73 / 74
+    "nf2_short_runs": sa.SceneSpec(n_frames=6, grid_nx=9, grid_ny=7, vis_window=2),      # one tile row; runs of 10..15
+}
+
+
+@pytest.mark.parametrize("name", list(MFMA_EDGES))
+@pytest.mark.parametrize("c", [1e-4, 10.0])
+def test_phases_on_mfma_tile_edges(orc, gpu, name, c):
+    sc = sa.generate_scene(MFMA_EDGES[name])
+    out = _phases(orc, gpu, sc, MFMA_EDGES[name].f0, c)
+    _check(out, sc.M, corr_tol=1e-7)
+
+
 RAGGED = {
     # ragged feature tracks: observations dropped at random, so that hardly two landmarks see the same frames and the
     # grouped Schur kernel works on unions of frame lists (zero blocks where a landmark misses a frame of its run)
