@@ -1191,6 +1191,15 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     long long tacc = 0;
 #endif
     MM_STAMP(0);
+#ifndef SRK_MM_NO_STAGGER
+    // Workgroups of equal length started together flush together: the fp64 atomics then queue at the memory side
+    // (~1.9 TB/s chip-wide; stamps: 24 us per flush, 15 us when the flushes are spread out) while the matrix pipes
+    // idle, and idle again while everybody multiplies.  When the grid is at least two rounds of workgroups, the first
+    // workgroup of a CU starts up to ~55 us late, by its place among its XCD's first workgroups, and the later ones
+    // inherit the offset (C3: Schur phase -2.7 %; tools/schur_ablate.sh with -DSRK_MM_NO_STAGGER).
+    if (blockIdx.x < 256 && gridDim.x >= 512)
+        for (int t = (blockIdx.x >> 3) & 15; t > 0; --t) __builtin_amdgcn_s_sleep(127);
+#endif
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
     const int nfu = grp_nf[blockIdx.x];
