@@ -41,6 +41,9 @@ def parse():
                     help="remove this fraction of the observations at random (ragged tracks; not the headline workload)")
     ap.add_argument("--schur-fp32", action="store_true",
                     help="opt-in mixed precision (fp32 run sums in the Schur kernel); never the headline configuration")
+    ap.add_argument("--sequential-attempts", action="store_true",
+                    help="one attempt slot (srk_ba_set_speculation off): kernels of different attempts never overlap, "
+                         "so per-kernel durations under rocprofv3 are those of the kernel alone (profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
     ap.add_argument("--no-dense-probe", action="store_true")
@@ -128,6 +131,8 @@ def main():
     ba.set_profile(0)  # the timed region carries no instrumentation; phases are timed in separate steps below
     if args.schur_fp32:
         ba.set_schur_precision(True)
+    if args.sequential_attempts:
+        ba.set_speculation(False)
     if world > 1:
         from surikatoko_amd.dist import make_allreduce_hook
         ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
@@ -318,7 +323,8 @@ def main():
                        "parallelism": f"landmark shards x{world}" if world > 1 else "single GPU",
                        "points_per_rank": shard.N, "obs_per_rank": shard.O, "rcs_dim": 10 * M - 7,
                        "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks,
-                       "lm_attempts": "two attempt slots: the next damping factor runs beside the current one and is "
+                       "lm_attempts": "one attempt at a time (--sequential-attempts)" if args.sequential_attempts else
+                                      "two attempt slots: the next damping factor runs beside the current one and is "
                                       "judged in the reference's order (srk_ba_set_speculation)"},
             "iterations_done": iterations,
             "attempts_per_iteration": attempts_timed / max(iterations, 1),
