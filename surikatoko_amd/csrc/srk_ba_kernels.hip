@@ -1323,29 +1323,37 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const int pb = r * PB;
             const int nb = np - pb < PB ? np - pb : PB;
             if (ypl < nb) {
+                // straight-line code: every lane loads and stores (a lane past the last column works on the padding
+                // column LDW - 1, which no flushed entry depends on) -- per-element branches made this a chain of nine
+                // LDS round trips, 1.7 us a round
                 const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]); // rows are 96 B: 16-byte aligned
                 const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
                 double w[NC][3];
+                int cc[NC];
 #pragma unroll
                 for (int i = 0; i < NC; ++i) {
                     const int col = lane + 64 * i;
-                    const double* wp = bw + 3 * ypl * LDW + col;
-                    const bool on = col < nf10 && !(ragged && !((mask_pre >> (col / 10)) & 1u)); // else: zero blocks
+                    cc[i] = col < nf10 ? col : LDW - 1;
+                    const double* wp = bw + 3 * ypl * LDW + cc[i];
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) w[i][m] = on ? wp[m * LDW] : 0.0;
+                    for (int m = 0; m < 3; ++m) w[i][m] = wp[m * LDW];
                 }
 #pragma unroll
                 for (int i = 0; i < NC; ++i) {
                     const int col = lane + 64 * i;
-                    if (col >= nf10) continue;
-                    double* wp = bw + 3 * ypl * LDW + col;
-                    double* yp = by + 3 * ypl * LDW + col;
-                    const double w0 = w[i][0], w1 = w[i][1], w2 = w[i][2];
-                    if (ragged) { wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2; } // a missed frame's stale W becomes zero
+                    double* wp = bw + 3 * ypl * LDW + cc[i];
+                    double* yp = by + 3 * ypl * LDW + cc[i];
+                    double w0 = w[i][0], w1 = w[i][1], w2 = w[i][2];
+                    if (ragged) { // a frame the landmark misses: zero blocks instead of the earlier round's stale W
+                        const bool on = (mask_pre >> (col / 10)) & 1u;
+                        w0 = on ? w0 : 0.0; w1 = on ? w1 : 0.0; w2 = on ? w2 : 0.0;
+                        wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2;
+                    }
                     yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
                     yp[LDW] = e23.y * w0 + e45.x * w1 + e45.y * w2;
                     yp[2 * LDW] = e67.x * w0 + e67.y * w1 + e89.x * w2;
-                    racc[i] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
+                    const double rr = w0 * e89.y + w1 * eab.x + w2 * eab.y;
+                    racc[i] += col < nf10 ? rr : 0.0;
                 }
             }
             // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
