@@ -1144,23 +1144,38 @@ typedef double srk_double4 __attribute__((ext_vector_type(4)));
 // the K = 4 steps of one round for a wave with NS tiles: operands of all tiles first, then the MFMAs (branch-free)
 template <int NS>
 __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, const double* by,
-                                               const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int ksteps)
+                                               const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int lbase)
 {
-    static_assert(NS % 4 == 0, "tiles go four at a time");
-    for (int ks = 0; ks < ksteps; ++ks) {
+    static_assert(NS == 8, "two half steps of four tiles");
+    // half step hs = (K step hs / 2, tiles 4 (hs & 1) .. + 3).  The operand addresses (lane part + wave-uniform tile
+    // offset) are formed again at every half step -- opaque to the compiler, which would otherwise keep all 16 of them
+    // in VGPRs -- so that a second operand set fits the 128 registers: the next half step's LDS reads are in flight
+    // while this one's four MFMAs issue.
+    auto load = [&](double (&a)[4], double (&b)[4], int hs) {
+        int lb = lbase;
+        asm volatile("" : "+v"(lb));
+        const int ko = (hs >> 1) * 4 * SRK_MM_LDW, s0 = (hs & 1) * 4;
 #pragma unroll
-        for (int s0 = 0; s0 < NS; s0 += 4) { // four tiles at a time: eight operand registers live, not 2 NS
-            double av[4], bv[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                av[s] = bw[ks * 4 * SRK_MM_LDW + ta[s0 + s]];
-                bv[s] = by[ks * 4 * SRK_MM_LDW + tb[s0 + s]];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc[s0 + s], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            a[s] = bw[ko + lb + ta[s0 + s]];
+            b[s] = by[ko + lb + tb[s0 + s]];
         }
-    }
+    };
+    auto mac = [&](const double (&a)[4], const double (&b)[4], int hs) {
+        const int s0 = (hs & 1) * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[s0 + s], 0, 0, 0);
+    };
+    // always the three K steps of a full round: in a short last round the k rows of the missing landmarks are zeros
+    // (y_round), and one code path keeps the accumulators in place
+    double a0[4], b0[4], a1[4], b1[4];
+    load(a0, b0, 0);
+    load(a1, b1, 1); mac(a0, b0, 0);
+    load(a0, b0, 2); mac(a1, b1, 1);
+    load(a1, b1, 3); mac(a0, b0, 2);
+    load(a0, b0, 4); mac(a1, b1, 3);
+    load(a1, b1, 5); mac(a0, b0, 4);
+    mac(a1, b1, 5);
 }
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
@@ -1434,12 +1449,10 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const double* bw = sBuf + wi * WB;
             const double* by = sBuf + (3 + (r & 1)) * WB;
             wi = wi == 2 ? 0 : wi + 1;
-            const int nb = np - r * PB < PB ? np - r * PB : PB;
-            const int ksteps = (3 * nb + 3) >> 2;
 #ifdef SRK_SCH_NOACC
             if (d.N < 0)
 #endif
-            schur_mm_steps<SRK_MM_SLOTS>(acc, bw + lbase, by + lbase, ta, tb, ksteps); // idle slots multiply tile (0, 0)
+            schur_mm_steps<SRK_MM_SLOTS>(acc, bw, by, ta, tb, lbase); // idle slots multiply tile (0, 0)
             MM_ACC(0, 6, tacc);
             lds_barrier();
             MM_ACC(0, 7, tacc);
