@@ -1402,7 +1402,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (r + 3 < R) load_round(r + 3);
             MM_ACC(64 * SRK_MM_CW, 11, tacc);
             wi = wi == 2 ? 0 : wi + 1;
+#ifndef SRK_MM_NO_ROUND_BARRIER // ablation only (results are wrong without it): what the per-round synchronisation costs
             lds_barrier(); // the products of round r; W of round r + 2 and Y of round r + 1 are visible
+#endif
             MM_ACC(64 * SRK_MM_CW, 12, tacc);
         }
 #pragma unroll
@@ -1454,7 +1456,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #endif
             schur_mm_steps<SRK_MM_SLOTS>(acc, bw, by, ta, tb, lbase); // idle slots multiply tile (0, 0)
             MM_ACC(0, 6, tacc);
+#ifndef SRK_MM_NO_ROUND_BARRIER
             lds_barrier();
+#endif
             MM_ACC(0, 7, tacc);
         }
         MM_STAMP(3);
