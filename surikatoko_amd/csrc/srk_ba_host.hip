@@ -98,6 +98,7 @@ struct srk_ba {
     int profile_level = 0; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
     int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
+    bool lean_resets = false; // srk_ba_optimize: no per-attempt memsets (see phase_solve)
 };
 
 #define HIPCHK(h, expr)                                                                              \
@@ -898,7 +899,7 @@ static int phase_error(srk_ba* h, int which, double* err_host, bool with_status 
                      P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->A->err_partial), np, P<double>(h->A->err_out),
                      h->jac_fused ? P<int32_t>(h->wg_jmin) : nullptr);
     if (with_status)
-        srk_launch_status_pack(s, P<int>(h->A->info), reinterpret_cast<const int*>(reinterpret_cast<char*>(h->A->acc.p) + 8 * 3 * d.Ns),
+        srk_launch_status_pack(s, P<int>(h->A->info), reinterpret_cast<int*>(reinterpret_cast<char*>(h->A->acc.p) + 8 * 3 * d.Ns),
                                P<double>(h->A->err_out));
     HIPCHK(h, hipGetLastError());
     int rc = exchange(h, P<double>(h->A->err_out), with_status ? 3 : 1);
@@ -939,8 +940,7 @@ static int phase_schur(srk_ba* h, double c)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
-    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->A->S));
-    HIPCHK(h, hipMemsetAsync(h->A->rhs.p, 0, 8 * d.ld, s));
+    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->A->S), P<double>(h->A->rhs)); // S band and rhs
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S),
                              P<double>(h->A->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
@@ -983,7 +983,9 @@ static void launch_solve(srk_ba* h, SrkSolveProf* prof)
 static int phase_solve(srk_ba* h, bool profile)
 {
     const SrkDims& d = h->d;
-    HIPCHK(h, hipMemsetAsync(h->A->info.p, 0, 4, h->stream));
+    // inside the LM loop the status words and the point accumulators are left cleared by the kernels that consume them
+    // (k_status_pack, k_point_update); the step-wise entry points clear them here
+    if (!h->lean_resets) HIPCHK(h, hipMemsetAsync(h->A->info.p, 0, 4, h->stream));
     h->A->solve_prof = SrkSolveProf{};
     if (profile) {
         size_t need = (size_t)(2 * (2 * (d.ld / SRK_CHOL_NB) + 64)); // every level of a nested plan included
@@ -1012,7 +1014,7 @@ static int phase_backsub_apply(srk_ba* h, double c)
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
     int cur = h->cur, tr = h->A->trial;
-    HIPCHK(h, hipMemsetAsync(h->A->acc.p, 0, 8 * 3 * d.Ns + 64, s));
+    if (!h->lean_resets) HIPCHK(h, hipMemsetAsync(h->A->acc.p, 0, 8 * 3 * d.Ns + 64, s));
     srk_launch_backsub(s, d, c, P<int32_t>(h->obs_frame), P<int32_t>(h->obs_pt), P<double>(h->W), P<double>(h->Vg),
                        P<double>(h->A->dc), P<double>(h->A->acc), P<double>(h->pts[cur]), P<double>(h->pts[tr]),
                        P<double>(h->A->dx));
@@ -1115,6 +1117,18 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     };
 #define EVREC(i) do { if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[i], s)); } while (0)
 
+    // clear the status words and point accumulators of every slot once; from here on the kernels keep them clear
+    for (auto& a : h->att)
+        if (a.allocated) {
+            HIPCHK(h, hipMemsetAsync(a.info.p, 0, 4, s));
+            HIPCHK(h, hipMemsetAsync(a.acc.p, 0, 8 * 3 * d.Ns + 64, s));
+        }
+    HIPCHK(h, hipStreamSynchronize(s)); // the second slot's stream starts after this
+    struct LeanGuard {
+        srk_ba* h;
+        explicit LeanGuard(srk_ba* hh) : h(hh) { h->lean_resets = true; }
+        ~LeanGuard() { h->lean_resets = false; }
+    } lean_guard(h);
     double hessian_factor = (double)0.0001f; // :723 (float literal)
     // seen_points_count over all shards (:483, :726)
     // once per uploaded scene: it does not change between optimise calls

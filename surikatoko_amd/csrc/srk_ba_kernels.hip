@@ -1624,7 +1624,7 @@ __global__ __launch_bounds__(256) void k_backsub_obs(SrkDims d, const int32_t* _
 }
 
 // dx_i = -E^-1 (F_i dc + g_i)  (:1951), zero when E is not invertible (:1939-1943); X_trial = X + dx (:2012-2016)
-__global__ void k_point_update(SrkDims d, double c, const double* __restrict__ Vg, const double* __restrict__ acc,
+__global__ void k_point_update(SrkDims d, double c, const double* __restrict__ Vg, double* __restrict__ acc,
                                const double* __restrict__ pts, double* __restrict__ pts_trial, double* __restrict__ dx,
                                int* __restrict__ info)
 {
@@ -1640,6 +1640,7 @@ __global__ void k_point_update(SrkDims d, double c, const double* __restrict__ V
             if (!isfinite(dxi[m])) atomicOr(info, 2); // :1953-1954
         }
     }
+    acc[pt] = acc[d.Ns + pt] = acc[2 * d.Ns + pt] = 0.0; // consumed: k_backsub_obs of the slot's next attempt adds from zero
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         dx[3 * pt + m] = dxi[m];
@@ -1651,7 +1652,8 @@ void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t
                         const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
                         double* pts_trial, double* dx)
 {
-    // acc is zeroed by the caller (hipMemsetAsync) and the info word is the int right behind acc
+    // acc must be zero on entry (the caller's memset, or k_point_update of the slot's previous attempt); the info word is
+    // the int right behind acc
     if (d.O > 0) {
         int64_t blocks = (d.O + 255) / 256;
         hipLaunchKernelGGL(k_backsub_obs, dim3((unsigned)blocks), dim3(256), 0, s, d, obs_frame, obs_pt, W, dc, acc);
@@ -1846,13 +1848,16 @@ __global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __
 }
 
 // {solver info, point-update info} next to the error scalar: one 24-byte read-back per LM attempt
-__global__ void k_status_pack(const int* __restrict__ info, const int* __restrict__ info2, double* __restrict__ out)
+// the status words are cleared once they are packed, ready for the slot's next attempt (no memset launches in the LM loop)
+__global__ void k_status_pack(int* __restrict__ info, int* __restrict__ info2, double* __restrict__ out)
 {
     out[1] = (double)info[0];
     out[2] = (double)info2[0];
+    info[0] = 0;
+    info2[0] = 0;
 }
 
-void srk_launch_status_pack(hipStream_t s, const int* info, const int* info2, double* out)
+void srk_launch_status_pack(hipStream_t s, int* info, int* info2, double* out)
 {
     hipLaunchKernelGGL(k_status_pack, dim3(1), dim3(1), 0, s, info, info2, out);
 }
@@ -1895,17 +1900,19 @@ void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const d
 // The reduced camera system is non-zero only where two frames share a landmark.  env_col[t] is the first column
 // (multiple of 256) that can be non-zero in the 128-row tile row t; Cholesky fill stays inside that skyline.
 // zero / pack / unpack touch only rows' segments [env_col[t], 128 (t + 1)) -- the lower triangle inside the skyline.
-__global__ __launch_bounds__(256) void k_env_zero(int64_t ld, const int64_t* __restrict__ env_col, double* __restrict__ S)
+__global__ __launch_bounds__(256) void k_env_zero(int64_t ld, const int64_t* __restrict__ env_col, double* __restrict__ S,
+                                                  double* __restrict__ rhs /* zeroed too when given */)
 {
     int64_t t = blockIdx.y;
     int64_t c0 = env_col[t], c1 = 128 * (t + 1);
     int64_t row = 128 * t + blockIdx.x;
+    if (rhs && threadIdx.x == 0) rhs[row] = 0.0;
     double* p = S + row * ld;
     for (int64_t c = c0 + 2 * threadIdx.x; c < c1; c += 512) *reinterpret_cast<double2*>(p + c) = make_double2(0.0, 0.0);
 }
-void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S)
+void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S, double* rhs)
 {
-    hipLaunchKernelGGL(k_env_zero, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, S);
+    hipLaunchKernelGGL(k_env_zero, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, S, rhs);
 }
 
 // pack: out[env_off[t] + r * w + (c - c0)] = S[row][c], w = c1 - c0 ; dir = 0 pack, 1 unpack

@@ -79,11 +79,11 @@ int64_t srk_error_partials_staged(const SrkDims& d); // partial sums written whe
 void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const double* cam, const int32_t* obs_frame,
                             const int32_t* obs_pt, const double* obs_uv, double z_tol /* < 0: keep every observation */,
                             double* partial /* 2 n_partial */, int32_t n_partial, double* out2 /* {error, count} */);
-void srk_launch_status_pack(hipStream_t s, const int* info, const int* info2, double* out /* [3]: out[1..2] written */);
+void srk_launch_status_pack(hipStream_t s, int* info, int* info2, double* out /* [3]: out[1..2] written; info words cleared */);
 void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full);
 void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
 
-void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S);
+void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S, double* rhs /* zeroed too, or null */);
 void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
                          double* packed, int dir);
 void srk_launch_band_pack(hipStream_t s, int64_t ld, const int64_t* band_col, const int64_t* band_off, double* S,
