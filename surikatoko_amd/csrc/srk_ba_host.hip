@@ -897,10 +897,8 @@ static int phase_error(srk_ba* h, int which, double* err_host, bool with_status 
     int32_t np = srk_error_partials(d);
     srk_launch_error(s, d, P<double>(h->pts[which]), P<double>(h->cam[which]), P<int32_t>(h->obs_frame),
                      P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->A->err_partial), np, P<double>(h->A->err_out),
-                     h->jac_fused ? P<int32_t>(h->wg_jmin) : nullptr);
-    if (with_status)
-        srk_launch_status_pack(s, P<int>(h->A->info), reinterpret_cast<int*>(reinterpret_cast<char*>(h->A->acc.p) + 8 * 3 * d.Ns),
-                               P<double>(h->A->err_out));
+                     h->jac_fused ? P<int32_t>(h->wg_jmin) : nullptr, with_status ? P<int>(h->A->info) : nullptr,
+                     with_status ? reinterpret_cast<int*>(reinterpret_cast<char*>(h->A->acc.p) + 8 * 3 * d.Ns) : nullptr);
     HIPCHK(h, hipGetLastError());
     int rc = exchange(h, P<double>(h->A->err_out), with_status ? 3 : 1);
     if (rc != SRK_OK) return rc;
@@ -984,7 +982,7 @@ static int phase_solve(srk_ba* h, bool profile)
 {
     const SrkDims& d = h->d;
     // inside the LM loop the status words and the point accumulators are left cleared by the kernels that consume them
-    // (k_status_pack, k_point_update); the step-wise entry points clear them here
+    // (k_error_final, k_point_update); the step-wise entry points clear them here
     if (!h->lean_resets) HIPCHK(h, hipMemsetAsync(h->A->info.p, 0, 4, h->stream));
     h->A->solve_prof = SrkSolveProf{};
     if (profile) {
@@ -1026,9 +1024,9 @@ static int phase_cam_apply(srk_ba* h)
 {
     int cur = h->cur, tr = h->A->trial;
     srk_launch_cam_apply(h->stream, h->d.M, P<double>(h->camR[cur]), P<double>(h->camT[cur]), P<double>(h->A->dc),
-                         P<double>(h->camR[tr]), P<double>(h->camT[tr]));
+                         P<double>(h->camR[tr]), P<double>(h->camT[tr]), P<double>(h->K), h->f0, P<double>(h->cam[tr]));
     HIPCHK(h, hipGetLastError());
-    return compute_cam_packs(h, tr);
+    return SRK_OK;
 }
 
 extern "C" {

@@ -20,15 +20,9 @@ __device__ __forceinline__ bool srk_is_fixed_var(int64_t var, int comp)
 }
 
 // ------------------------------------------------------------------ camera pack
-__global__ void k_cam_pack(int32_t M, const double* __restrict__ R, const double* __restrict__ T,
-                           const double* __restrict__ K, double f0, double* __restrict__ pack)
+// one camera's pack from its inverse pose (r, t) and intrinsics k; also called by k_cam_apply on the pose it has just made
+__device__ __forceinline__ void cam_pack_one(const double* r, const double* t, const double* k, double f0, double* p)
 {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M) return;
-    const double* r = R + 9 * (int64_t)j;
-    const double* t = T + 3 * (int64_t)j;
-    const double* k = K + 9 * (int64_t)j;
-    double* p = pack + (int64_t)SRK_CAM_PACK * j;
     for (int i = 0; i < 9; ++i) { p[i] = r[i]; p[12 + i] = k[i]; }
     for (int i = 0; i < 3; ++i) p[9 + i] = t[i];
     for (int a = 0; a < 3; ++a)
@@ -50,6 +44,13 @@ __global__ void k_cam_pack(int32_t M, const double* __restrict__ R, const double
     p[45] = v0 / (f0 * fy);
     p[46] = 1 / f0;
     p[47] = f0;
+}
+__global__ void k_cam_pack(int32_t M, const double* __restrict__ R, const double* __restrict__ T,
+                           const double* __restrict__ K, double f0, double* __restrict__ pack)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    cam_pack_one(R + 9 * (int64_t)j, T + 3 * (int64_t)j, K + 9 * (int64_t)j, f0, pack + (int64_t)SRK_CAM_PACK * j);
 }
 
 void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double* T, const double* K, double f0,
@@ -1668,7 +1669,8 @@ void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t
 // ------------------------------------------------------------------ K6: camera update
 // T_direct += dT ; R_direct <- Rodrigues(dW) R_direct unless |dW| ~ 0 ; store the inverse pose (:2021-2062, :59-92)
 __global__ void k_cam_apply(int32_t M, const double* __restrict__ R, const double* __restrict__ T,
-                            const double* __restrict__ dc, double* __restrict__ Rn, double* __restrict__ Tn)
+                            const double* __restrict__ dc, double* __restrict__ Rn, double* __restrict__ Tn,
+                            const double* __restrict__ K, double f0, double* __restrict__ pack /* of the new pose, or null */)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
@@ -1705,12 +1707,19 @@ __global__ void k_cam_apply(int32_t M, const double* __restrict__ R, const doubl
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) ro[3 * a + b] = Rnew[3 * b + a];
     for (int a = 0; a < 3; ++a) to[a] = -(ro[3 * a] * Td[0] + ro[3 * a + 1] * Td[1] + ro[3 * a + 2] * Td[2]);
+    if (pack) { // the same values k_cam_pack would read back
+        double rl[9], tl[3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) rl[3 * a + b] = Rnew[3 * b + a];
+        for (int a = 0; a < 3; ++a) tl[a] = -(rl[3 * a] * Td[0] + rl[3 * a + 1] * Td[1] + rl[3 * a + 2] * Td[2]);
+        cam_pack_one(rl, tl, K + 9 * (int64_t)j, f0, pack + (int64_t)SRK_CAM_PACK * j);
+    }
 }
 
 void srk_launch_cam_apply(hipStream_t s, int32_t M, const double* R, const double* T, const double* dc, double* Rn,
-                          double* Tn)
+                          double* Tn, const double* K, double f0, double* pack)
 {
-    hipLaunchKernelGGL(k_cam_apply, dim3((M + 63) / 64), dim3(64), 0, s, M, R, T, dc, Rn, Tn);
+    hipLaunchKernelGGL(k_cam_apply, dim3((M + 63) / 64), dim3(64), 0, s, M, R, T, dc, Rn, Tn, K, f0, pack);
 }
 
 // ------------------------------------------------------------------ K1: reprojection error
@@ -1832,8 +1841,11 @@ __global__ __launch_bounds__(256) void k_error_score(int64_t O, const double* __
 }
 
 // fixed-order final sum: the LM accept/reject decision must not depend on atomic arrival order
+// info / info2 given: {solver info, point-update info} go next to the error scalar (one 24-byte read-back per LM attempt)
+// and are cleared, ready for the slot's next attempt (no memset launches in the LM loop)
 __global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __restrict__ partial,
-                                                     double* __restrict__ out)
+                                                     double* __restrict__ out, int* __restrict__ info,
+                                                     int* __restrict__ info2)
 {
     __shared__ double red[256];
     double s = 0;
@@ -1844,22 +1856,15 @@ __global__ __launch_bounds__(256) void k_error_final(int32_t n, const double* __
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         lds_barrier();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
-}
-
-// {solver info, point-update info} next to the error scalar: one 24-byte read-back per LM attempt
-// the status words are cleared once they are packed, ready for the slot's next attempt (no memset launches in the LM loop)
-__global__ void k_status_pack(int* __restrict__ info, int* __restrict__ info2, double* __restrict__ out)
-{
-    out[1] = (double)info[0];
-    out[2] = (double)info2[0];
-    info[0] = 0;
-    info2[0] = 0;
-}
-
-void srk_launch_status_pack(hipStream_t s, int* info, int* info2, double* out)
-{
-    hipLaunchKernelGGL(k_status_pack, dim3(1), dim3(1), 0, s, info, info2, out);
+    if (threadIdx.x == 0) {
+        out[0] = red[0];
+        if (info) {
+            out[1] = (double)info[0];
+            out[2] = (double)info2[0];
+            info[0] = 0;
+            info2[0] = 0;
+        }
+    }
 }
 
 int32_t srk_error_partials(const SrkDims& d)
@@ -1872,18 +1877,18 @@ int64_t srk_error_partials_staged(const SrkDims& d) { return d.O > 0 ? (d.O + SR
 
 void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                       const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
-                      int32_t n_partial, double* err_out, const int32_t* wg_jmin)
+                      int32_t n_partial, double* err_out, const int32_t* wg_jmin, int* info, int* info2)
 {
     if (wg_jmin && d.O > 0) { // staged cameras: one partial sum per run of SRK_JF_OBS observations
         const int64_t nb = srk_error_partials_staged(d);
         hipLaunchKernelGGL(k_error_staged, dim3((unsigned)nb), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv, wg_jmin,
                            partial);
-        hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, (int32_t)nb, partial, err_out);
+        hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, (int32_t)nb, partial, err_out, info, info2);
         return;
     }
     hipLaunchKernelGGL(k_error, dim3((unsigned)n_partial), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
                        partial);
-    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, err_out);
+    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, err_out, info, info2);
 }
 
 void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const double* cam, const int32_t* obs_frame,
@@ -1892,9 +1897,11 @@ void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const d
 {
     hipLaunchKernelGGL(k_error_score, dim3((unsigned)n_partial), dim3(256), 0, s, O, pts, cam, obs_frame, obs_pt, obs_uv,
                        z_tol, partial);
-    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, out2);
-    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial + n_partial, out2 + 1);
+    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial, out2, (int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_error_final, dim3(1), dim3(256), 0, s, n_partial, partial + n_partial, out2 + 1, (int*)nullptr,
+                       (int*)nullptr);
 }
+
 
 // ------------------------------------------------------------------ skyline (envelope) helpers for the RCS
 // The reduced camera system is non-zero only where two frames share a landmark.  env_col[t] is the first column

@@ -69,17 +69,17 @@ void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t
                         const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
                         double* pts_trial, double* dx);
 void srk_launch_cam_apply(hipStream_t s, int32_t M, const double* R, const double* T, const double* dc, double* Rn,
-                          double* Tn);
+                          double* Tn, const double* K, double f0, double* pack /* camera packs of the new poses, or NULL */);
 void srk_launch_error(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                       const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* partial,
                       int32_t n_partial, double* err_out,
-                      const int32_t* wg_jmin /* fused-Jacobian frame windows, or NULL: gather the cameras */);
+                      const int32_t* wg_jmin /* fused-Jacobian frame windows, or NULL: gather the cameras */,
+                      int* info = nullptr, int* info2 = nullptr /* given: packed into err_out[1..2] and cleared */);
 int32_t srk_error_partials(const SrkDims& d);
 int64_t srk_error_partials_staged(const SrkDims& d); // partial sums written when wg_jmin is given
 void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const double* cam, const int32_t* obs_frame,
                             const int32_t* obs_pt, const double* obs_uv, double z_tol /* < 0: keep every observation */,
                             double* partial /* 2 n_partial */, int32_t n_partial, double* out2 /* {error, count} */);
-void srk_launch_status_pack(hipStream_t s, int* info, int* info2, double* out /* [3]: out[1..2] written; info words cleared */);
 void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full);
 void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
 
