@@ -70,7 +70,7 @@ def cpu_baseline(sample_name):
     import surikatoko_amd as sa
     from oracle import oracle as orc
     spec = sa.CONFIGS[sample_name]
-    sc = sa.generate_scene(spec)
+    sc = sa.config_scene(sample_name)
     so = orc.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, sc.row_ptr, sc.obs_frame, sc.obs_uv)
     t0 = time.perf_counter()
     rc, rep = orc.compute_inplace(spec.f0, so, None, None, 1)
@@ -115,7 +115,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     spec = sa.CONFIGS[args.config]
-    scene = sa.generate_scene(spec)
+    scene = sa.config_scene(args.config)
     if args.drop > 0:
         scene = sa.drop_observations(scene, args.drop, seed=1)
     N_total, M, O_total = scene.N, scene.M, scene.O

@@ -5,9 +5,11 @@
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "flags.hpp"
+#include "scene_dump.hpp"
 #include "suriko_amd/bundle-adj-kanatani.hpp"
 
 #ifndef M_PI
@@ -29,6 +31,8 @@ int main(int argc, char** argv)
     const double noise_R_hi = fl.Double("noise_R_hi", 0.005), noise_x3D_hi = fl.Double("noise_x3D_hi", 0.005);
     const double allowed_repr_err = fl.Double("allowed_repr_err", 1e-5);
     const long max_iterations = fl.Int("max_iterations", 0); // harness addition: the reference has no cap
+    // harness additions: the scene handed to / returned by ComputeInplace, for the oracle comparison in tests/
+    const std::string dump_before = fl.String("dump_scene_before", ""), dump_after = fl.String("dump_scene_after", "");
     std::fprintf(stderr, "noise_x3D_hi=%g\nnoise_R_hi=%g\n", noise_x3D_hi, noise_R_hi);
 
     const double rot_radius = 15 * cx, ascentZ = 10 * cx; // :86-87
@@ -109,9 +113,11 @@ int main(int argc, char** argv)
     BundleAdjustmentKanatani ba;
     BundleAdjustmentKanataniTermCriteria term_crit;
     if (allowed_repr_err > 0) term_crit.AllowedReprojErrRelativeChange(allowed_repr_err); // :287-288
+    if (!dump_before.empty() && !DumpScene(dump_before, f0, map_noise, cams, track_rep, nullptr, &Ks)) return 3;
     std::fprintf(stderr, "start bundle adjustment...\n");
     bool op = ba.ComputeInplace(f0, map_noise, cams, track_rep, nullptr, &Ks, term_crit, max_iterations); // :291
     std::fprintf(stderr, "bundle adjustment finished with result: %d (%s)\n", (int)op, ba.OptimizationStatusString().c_str());
+    if (!dump_after.empty() && !DumpScene(dump_after, f0, map_noise, cams, track_rep, nullptr, &Ks)) return 3;
     const srk_ba_report& r = ba.Report();
     std::printf("{\"result\": %d, \"status\": \"%s\", \"iterations\": %lld, \"attempts\": %lld, \"err_initial\": %.17g, "
                 "\"err_final\": %.17g, \"frames\": %zu, \"points\": %zu}\n",

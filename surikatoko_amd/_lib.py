@@ -4,7 +4,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libsrk_ba.so")
+# SRK_BA_LIBRARY: development only (tools/*.sh load ablation / stamp builds from a temporary path, so that the product
+# library in the tree is never overwritten)
+_PATH = os.environ.get("SRK_BA_LIBRARY") or os.path.join(_HERE, "libsrk_ba.so")
 _lib = None
 
 

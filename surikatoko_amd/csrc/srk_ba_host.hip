@@ -70,6 +70,7 @@ struct srk_ba {
         DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv, packed;
         SrkChunkPlan plan;
         std::vector<DevBuf> plan_bufs;
+        std::vector<char> plan_zeroed;   // plan_bufs[i] is a matrix / vector that must be zero outside what a solve writes
         std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
         SrkSolveProf solve_prof;     // event pairs / flops of the last profiled solve
         double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
@@ -99,6 +100,10 @@ struct srk_ba {
     int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
     bool lean_resets = false; // srk_ba_optimize: no per-attempt memsets (see phase_solve)
+    // A failed factorisation (non-positive / non-finite pivot) leaves NaNs in the slot's system and chunk matrices, also
+    // OUTSIDE the parts the next attempt rewrites (k_panel's dead rows: 0 * NaN).  The flag makes the next entry point
+    // re-zero every slot's system and plan buffers (clear_poison) before anything is computed from them.
+    bool poisoned = false;
 };
 
 #define HIPCHK(h, expr)                                                                              \
@@ -412,6 +417,7 @@ static int make_plan(srk_ba* h, SrkChunkPlan& pl, int64_t ld, int64_t sepw, int6
     int64_t pos = 0;
     auto alloc = [&](size_t bytes, bool zero) -> void* {
         h->A->plan_bufs.emplace_back();
+        h->A->plan_zeroed.push_back(zero ? 1 : 0);
         if (dev_alloc(h, h->A->plan_bufs.back(), bytes) != SRK_OK) return nullptr;
         if (zero) hipMemsetAsync(h->A->plan_bufs.back().p, 0, bytes, h->stream);
         return h->A->plan_bufs.back().p;
@@ -485,6 +491,7 @@ static int build_chunk_plan(srk_ba* h)
     pl.child = nullptr;
     for (DevBuf& b : h->A->plan_bufs) dev_free(b);
     h->A->plan_bufs.clear();
+    h->A->plan_zeroed.clear();
     h->A->plan_children.clear();
     if (!h->use_envelope || !h->use_chunks) return SRK_OK;
     int64_t maxdist = 0;
@@ -840,6 +847,29 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     return SRK_OK;
 }
 
+// after a failed solve: every slot's system and zero-initialised plan buffers back to zeros (see srk_ba::poisoned)
+static int clear_poison(srk_ba* h)
+{
+    if (!h->poisoned) return SRK_OK;
+    const SrkDims& d = h->d;
+    for (auto& a : h->att) {
+        if (!a.allocated) continue;
+        HIPCHK(h, hipStreamSynchronize(a.stream));
+        HIPCHK(h, hipMemsetAsync(a.S.p, 0, (size_t)(8 * d.ld * d.ld), h->main_stream));
+        HIPCHK(h, hipMemsetAsync(a.rhs.p, 0, (size_t)(8 * d.ld), h->main_stream));
+        HIPCHK(h, hipMemsetAsync(a.wy.p, 0, (size_t)(16 * d.ld), h->main_stream));
+        HIPCHK(h, hipMemsetAsync(a.dc.p, 0, (size_t)(8 * d.ld), h->main_stream));
+        HIPCHK(h, hipMemsetAsync(a.dx.p, 0, d.N > 0 ? (size_t)(24 * d.N) : 8, h->main_stream));
+        HIPCHK(h, hipMemsetAsync(a.info.p, 0, 4, h->main_stream));
+        HIPCHK(h, hipMemsetAsync(a.acc.p, 0, (size_t)(8 * 3 * d.Ns + 64), h->main_stream));
+        for (size_t i = 0; i < a.plan_bufs.size(); ++i)
+            if (a.plan_zeroed[i]) HIPCHK(h, hipMemsetAsync(a.plan_bufs[i].p, 0, a.plan_bufs[i].bytes, h->main_stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->main_stream));
+    h->poisoned = false;
+    return SRK_OK;
+}
+
 extern "C" int srk_ba_reset_scene(srk_ba* h)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
@@ -847,6 +877,10 @@ extern "C" int srk_ba_reset_scene(srk_ba* h)
     select_attempt(h, 0);
     hipStream_t s = h->stream;
     HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // a speculative attempt may still read the current scene
+    {
+        int rcp = clear_poison(h);
+        if (rcp != SRK_OK) return rcp;
+    }
     h->cur = 0;
     h->att[0].trial = 1;
     h->att[1].trial = 2;
@@ -1053,7 +1087,9 @@ int srk_ba_phase_schur(srk_ba* h, double c)
     HIPCHK(h, hipSetDevice(h->device));
     select_attempt(h, 0); // the staged calls always work on attempt slot 0
     h->last_slot = 0;
-    int rc = phase_schur(h, c);
+    int rc = clear_poison(h);
+    if (rc != SRK_OK) return rc;
+    rc = phase_schur(h, c);
     if (rc != SRK_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SRK_OK;
@@ -1068,6 +1104,7 @@ int srk_ba_phase_solve(srk_ba* h)
     rc = read_info(h, &info);
     if (rc != SRK_OK) return rc;
     if (info && srk_debug()) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution)\n", info);
+    if (info) h->poisoned = true;
     return info ? 1 : 0;
 }
 int srk_ba_phase_backsub(srk_ba* h, double c)
@@ -1102,6 +1139,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     const SrkDims& d = h->d;
     auto t_begin = std::chrono::steady_clock::now();
     rep->world_scale = h->nrm.world_scale;
+    {
+        int rcp = clear_poison(h);
+        if (rcp != SRK_OK) return rcp;
+    }
 
     auto fail_device = [&](int rc) {
         rep->status = SRK_STATUS_DEVICE_ERROR;
@@ -1236,7 +1277,11 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
                         (long long)rep->attempts, sl,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_iter).count(),
                         hessian_factor, err_value, back.err, back.info, info2);
-            if (back.info != 0 || info2 != 0) { decrease = 2; return SRK_OK; } // solve failed (:807-808, :1912-1913, :1953-1954)
+            // Solve failed (:807-808, :1912-1913, :1953-1954).  The multiplicative damping keeps the diagonally scaled
+            // system's smallest eigenvalue >= c, so a Cholesky pivot can only fail where diag(G) holds an exact
+            // zero or a non-finite value -- exactly where the reference's Householder QR divides by a zero diagonal of R
+            // and returns non-finite numbers: both sides end with "hessian overflow".
+            if (back.info != 0 || info2 != 0) { h->poisoned = true; decrease = 2; return SRK_OK; }
             err_new = back.err;
             if (err_new - err_value < 0) { decrease = 1; accepted_slot = sl; return SRK_OK; } // :816-819
             // restore = drop the trial buffers (:823-826)
@@ -1250,9 +1295,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             have_prev = true;
             return SRK_OK;
         };
-        // several ranks: every rank takes the same decisions, so the exchanges of the two slots (each on its own packed
-        // buffer) are issued in the same order everywhere; slot 0's solve then overlaps slot 1's Schur sum and exchange
-        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0;
+        // several ranks: one attempt at a time.  (Every rank takes the same decisions, so the two slots' exchanges would be
+        // issued in the same order everywhere -- but that path has never run over RCCL on hardware: it stays off until
+        // an N > 1 run has covered it.)
+        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0 && !h->allreduce;
         bool spec_in_flight = false;
         int round = 0;
         const int64_t attempts_before = rep->attempts;
@@ -1335,7 +1381,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         err_value = err_new;
         hessian_factor /= 10; // :889
     }
-    if (spec_drain) HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // leave no speculative work behind
+    if (spec_drain) {
+        HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // leave no speculative work behind
+        if (h->att[1].host_back[1] != 0.0 || h->att[1].host_back[2] != 0.0) h->poisoned = true; // a dropped attempt that failed
+    }
     select_attempt(h, 0);
     rep->hessian_factor = hessian_factor;
     rep->optimized = result_true ? 1 : 0;

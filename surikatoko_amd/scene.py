@@ -30,7 +30,8 @@ class SceneSpec:
 
 # BASELINE.json configs (SURVEY 8d grid sizes); C1 is the labelled synthetic stand-in for the missing dino files
 CONFIGS = {
-    "C1_dino_standin": SceneSpec(36, 53, 94, vis_window=3),          # 36 cams, 4982 pts, 14946 obs
+    # 36 cams, 4983 pts; config_scene() trims the 4-frame windows to the 16432 observations the dino flagfile states
+    "C1_dino_standin": SceneSpec(36, 33, 151, vis_window=4),
     "C2_200cam_20kpt": SceneSpec(200, 200, 100, vis_window=20),      # 400k obs
     "C3_1kcam_100kpt": SceneSpec(1000, 400, 250, vis_window=20),     # 2M obs (headline)
     "C5_4kcam_1Mpt": SceneSpec(4000, 1000, 1000, vis_window=20),     # 20M obs
@@ -66,6 +67,32 @@ def generate_scene(spec: SceneSpec, with_gt=False):
     if with_gt:
         return sc, pts_gt, Rg, Tg
     return sc
+
+
+DINO_OBSERVATIONS = 16432  # cpp_impl/flagfile-demo-dino.txt:7 ("16432*0.01^2/600^2")
+
+
+def config_scene(name, with_gt=False):
+    """The scene of a BASELINE.json config.  C1 is the labelled synthetic stand-in for the oxfvisgeom dinosaur files
+    (not in the reference tree): 36 turntable cameras, 4983 points (demo-bundle-adj-dinosaur.cpp:97,116)
+    and exactly 16432 observations: 1483 landmarks keep their 4-frame window, the other 3500 lose its last frame
+    (a deterministic choice; every landmark keeps >= 3 consecutive frames)."""
+    spec = CONFIGS[name]
+    out = generate_scene(spec, with_gt=with_gt)
+    if name != "C1_dino_standin":
+        return out
+    from .ba import Scene
+    sc = out[0] if with_gt else out
+    N = sc.N
+    assert N == 4983 and sc.O == 4 * N
+    keep4 = (np.arange(N, dtype=np.int64) * 7919) % N < DINO_OBSERVATIONS - 3 * N
+    keep = np.ones(sc.O, dtype=bool)
+    keep[sc.row_ptr[1:][~keep4] - 1] = False
+    counts = np.where(keep4, 4, 3).astype(np.int64)
+    rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    trimmed = Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, rp, sc.obs_frame[keep], sc.obs_uv[keep])
+    assert trimmed.O == DINO_OBSERVATIONS
+    return (trimmed,) + tuple(out[1:]) if with_gt else trimmed
 
 
 def drop_observations(scene, fraction, seed=0, keep_min=2):

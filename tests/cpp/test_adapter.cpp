@@ -7,11 +7,14 @@
 #include <cstdio>
 #include <vector>
 
+#include "scene_dump.hpp"
 #include "suriko_amd/bundle-adj-kanatani.hpp"
 using namespace suriko_amd;
 
-int main()
+int main(int argc, char** argv)
 {
+    // optional: argv[1] / argv[2] = files receiving the container scene before / after ComputeInplace (tests/ runs the
+    // CPU oracle on the first and compares with the second)
     srk_scene_spec spec{};
     spec.n_frames = 9; spec.grid_nx = 7; spec.grid_ny = 6; spec.vis_window = 5;
     spec.half_extent_x = spec.half_extent_y = 1; spec.f0 = 1.0; spec.noise_x3d_hi = 0.005; spec.noise_r_hi = 0.005;
@@ -52,7 +55,9 @@ int main()
     double e_mvf = -1;
     if (!ba.ReprojErrorMvf(1.0, map, cams, rep, &sharedK, &e_mvf)) return 13;
     if (std::fabs(e_mvf - e0) > 1e-12 * std::fabs(e0)) return 14;
+    if (argc > 1 && !DumpScene(argv[1], 1.0, map, cams, rep, &sharedK, nullptr)) return 15;
     bool ok = ba.ComputeInplace(1.0, map, cams, rep, &sharedK, nullptr, crit);
+    if (argc > 2 && !DumpScene(argv[2], 1.0, map, cams, rep, &sharedK, nullptr)) return 15;
 
     // reference run through the C ABI on the flat arrays
     srk_ba* h = srk_ba_create(0);
@@ -72,10 +77,10 @@ int main()
         for (int e = 0; e < 9; ++e) maxd = std::fmax(maxd, std::fabs(cams[(size_t)j].R[(size_t)e] - R[9 * j + e]));
     std::printf("{\"ok\": %d, \"rc\": %d, \"status\": \"%s\", \"seen\": %zu, \"err0\": %.17g, \"err0_c\": %.17g, "
                 "\"err_final\": %.17g, \"err_final_c\": %.17g, \"iterations\": %lld, \"iterations_c\": %lld, \"maxdiff\": %.3e, "
-                "\"points\": %zu, \"vars\": %zu, \"normalized_vars\": %zu}\n",
+                "\"points\": %zu, \"vars\": %zu, \"normalized_vars\": %zu, \"attempts\": %lld}\n",
                 (int)ok, rc, ba.OptimizationStatusString().c_str(), seen, e0, repc.err_initial, ba.Report().err_final,
                 repc.err_final, (long long)ba.Report().iterations, (long long)repc.iterations, maxd, ba.PointsCount(),
-                ba.VarsCount(), ba.NormalizedVarsCount());
+                ba.VarsCount(), ba.NormalizedVarsCount(), (long long)ba.Report().attempts);
     bool caught = false;
     try { ba.ComputeInplace(1.0, map, cams, rep, nullptr, nullptr, crit); } catch (const std::invalid_argument&) { caught = true; }
     srk_ba_destroy(h);

@@ -254,6 +254,104 @@ def test_singular_point_blocks_are_skipped(orc, gpu):
         assert np.any(out["corr_o"][3 * i:3 * i + 3] != 0)
 
 
+def _without_frame(sc, frame):
+    keep = sc.obs_frame != frame
+    counts = np.add.reduceat(keep.astype(np.int64), sc.row_ptr[:-1])
+    return sa.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, np.concatenate([[0], np.cumsum(counts)]),
+                    sc.obs_frame[keep], sc.obs_uv[keep])
+
+
+def test_failed_solve_is_hessian_overflow_as_in_the_reference_and_leaves_no_residue(orc, gpu):
+    """When does the Cholesky that replaces the reference's Householder QR (bundle-adj-kanatani.cpp:1911) fail, and what
+    happens then?  The damping is multiplicative on both diagonals (:1818-1819, :1830-1831), so the reduced system is
+    >= c diag(G): scaled to a unit diagonal its smallest eigenvalue is >= c >= 1e-4 and a pivot cannot turn
+    non-positive through rounding.  A pivot fails only where diag(G) holds an exact zero -- e.g. a frame that observes
+    nothing -- and there the reference's QR divides by a zero diagonal entry of R, its solution is not finite
+    (:1912-1913) and ComputeInplace ends with "hessian overflow" after that one attempt.  Chosen behaviour = the same:
+    status, result, iteration and attempt counts of the oracle's QR restatement.
+    The failed factorisation leaves NaNs in the slot's matrices (also outside the parts a later attempt rewrites): the
+    next run on the same handle -- after a reset and after a fresh upload -- must be clean."""
+    spec = sa.SceneSpec(n_frames=7, grid_nx=6, grid_ny=5, vis_window=4)
+    good = sa.generate_scene(spec)
+    bad = _without_frame(good, 4)
+    assert np.diff(bad.row_ptr).min() >= 2
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, bad, spec.f0, allowed=1e-12, max_factor=1e6, max_iterations=30)
+    assert rc_o == 1 and orc.status_string(rep_o.status) == "hessian overflow"
+    assert not ok and sa.status_string(rep.status) == "hessian overflow"
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts) == (0, 1)
+    assert rep.err_final == rep.err_initial == pytest.approx(rep_o.err_initial, rel=1e-12)
+    # the scene is handed back unchanged (up to the normalise / revert round trip), as the reference restores its backup
+    assert np.abs(sg.points - bad.points).max() < 1e-9 and np.abs(sg.cam_T - bad.cam_T).max() < 1e-9
+    # same handle, same (failing) scene again after a reset: still the same answer, no crash
+    gpu.reset()
+    assert not gpu.optimize(None, max_iterations=5) and gpu.OptimizationStatusString() == "hessian overflow"
+    # and a good scene afterwards runs exactly as on a fresh handle: nothing of the failed solve survives
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, good, spec.f0, allowed=1e-12, max_factor=1e6, max_iterations=30)
+    assert ok == (rc_o == 0) and sa.status_string(rep.status) == orc.status_string(rep_o.status)
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+
+
+def test_failed_solve_on_a_loop_closure_scene_then_reset(orc, gpu):
+    """a non-monotone skyline (the last frames see the landmarks of the first ones: a loop closure) makes
+    k_panel sweep rows whose own skyline starts further right; after a failed factorisation those rows hold NaNs outside
+    what the next attempt rewrites.  Staged calls: fail a solve, then repair the scene on the same handle (upload keeps
+    the allocations) and compare a full run with the oracle."""
+    spec = sa.SceneSpec(n_frames=40, grid_nx=12, grid_ny=10, vis_window=6)
+    sc = sa.generate_scene(spec)
+    # loop closure: the landmarks of the first window are also seen by the last two frames
+    rp, fr, uv = sc.row_ptr, sc.obs_frame, sc.obs_uv
+    sc_gt, pts_gt, Rg, Tg = sa.generate_scene(spec, with_gt=True)
+    f_new, uv_new, cnt = [], [], []
+    for i in range(sc.N):
+        o = slice(rp[i], rp[i + 1])
+        f_i, uv_i = list(fr[o]), [tuple(x) for x in uv[o]]
+        if fr[rp[i]] == 0:
+            for j in (38, 39):
+                if j not in f_i:
+                    X = Rg[j].reshape(3, 3) @ pts_gt[i] + Tg[j]
+                    Kj = sc.K[j].reshape(3, 3)
+                    p = Kj @ X
+                    f_i.append(j)
+                    uv_i.append((spec.f0 * p[0] / p[2], spec.f0 * p[1] / p[2]))
+        order = np.argsort(f_i)
+        f_new += [f_i[k] for k in order]
+        uv_new += [uv_i[k] for k in order]
+        cnt.append(len(f_i))
+    loop = sa.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, 0, np.concatenate([[0], np.cumsum(cnt)]),
+                    np.array(f_new, dtype=np.int32), np.array(uv_new))
+    bad = _without_frame(loop, 20)
+    assert gpu.upload(spec.f0, bad)
+    gpu.phase_derivatives()
+    gpu.phase_schur(1e-4)
+    assert not gpu.phase_solve()          # zero pivot in frame 20's block
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, loop, spec.f0, allowed=1e-10, max_factor=1e6, max_iterations=6)
+    assert ok == (rc_o == 0) and sa.status_string(rep.status) == orc.status_string(rep_o.status)
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts) and rep.iterations >= 1
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+
+
+def test_indefinite_matrix_is_reported_by_the_solver(gpu):
+    """The solver itself: a symmetric matrix with one slightly negative eigenvalue is reported (info), never 'solved'."""
+    rng = np.random.RandomState(5)
+    n = 200
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    ev = np.linspace(1.0, 3.0, n)
+    ev[17] = -1e-6
+    A = (Q * ev) @ Q.T
+    A = 0.5 * (A + A.T)
+    ok, x, _ = gpu.dense_spd_solve(A, rng.randn(n))
+    assert not ok
+    ev[17] = 1e-6                          # barely positive definite: solved, to the accuracy its conditioning allows
+    A = (Q * ev) @ Q.T
+    A = 0.5 * (A + A.T)
+    b = rng.randn(n)
+    ok, x, _ = gpu.dense_spd_solve(A, b)
+    assert ok and np.abs(A @ x - b).max() < 1e-8 * np.abs(x).max()
+
+
 def test_shared_k_mode(orc, gpu):
     """multi-view-factorization call contract: shared K, f0 = 1 (multi-view-factorization.cpp:387-391)."""
     sc = sa.generate_scene(sa.SceneSpec(n_frames=7, grid_nx=6, grid_ny=4, vis_window=4, f0=1.0))
@@ -360,6 +458,57 @@ def test_reproj_error_api(orc, gpu):
     assert seen == so == sc.O
     assert e == pytest.approx(eo, rel=1e-12)
     assert gpu.ReprojErrorPixPerPoint(e, seen) == pytest.approx(spec.f0 * np.sqrt(eo / so), rel=1e-12)
+
+
+# ------------------------------------------------------------------ BASELINE configs 1 and 2 at full size vs the oracle
+
+@pytest.mark.parametrize("dense_literal", [False, True])
+def test_c1_dino_standin_end_to_end_vs_oracle(orc, gpu, dense_literal):
+    """BASELINE config 1 (demo-dino: 36 cams / 4983 pts / 16432 obs; the labelled synthetic stand-in, the oxfvisgeom
+    files are not in the reference tree) end to end with the dino flagfile's criteria (--f0=600
+    --allowed_repr_err=4.56e-8, cpp_impl/flagfile-demo-dino.txt:6-11; call at demo-bundle-adj-dinosaur.cpp:232-238)
+    against the oracle, once with its block-sparse storage and once with the reference's literal dense storage and
+    per-point n x n product (bundle-adj-kanatani.cpp:581,1891; n = 353): same result, status, iteration / attempt
+    counts, error rel 1e-6, scene abs 1e-6."""
+    sc = sa.config_scene("C1_dino_standin")
+    assert (sc.M, sc.N, sc.O) == (36, 4983, 16432)
+    so = _orc_scene(orc, sc)
+    rc_o, rep_o = orc.compute_inplace(600.0, so, 4.56e-8, None, 0, dense_literal=dense_literal)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(4.56e-8)
+    sg = sc.copy()
+    ok = gpu.ComputeInplace(600.0, sg, crit)
+    rep = gpu.report
+    assert ok == (rc_o == 0)
+    assert sa.status_string(rep.status) == orc.status_string(rep_o.status) == "small relative err change"
+    assert rep.seen == rep_o.seen == 16432
+    assert rep.err_initial == pytest.approx(rep_o.err_initial, rel=1e-12)
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+    assert rep.iterations >= 10
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+    assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+    assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
+
+
+def test_c2_full_size_blocks_system_and_one_iteration_vs_oracle(orc, gpu):
+    """BASELINE config 2 (200 cams / 20k pts / 400k obs) at full size against the oracle: derivative blocks rel 1e-12,
+    reduced camera system (n = 1993) and rhs rel 1e-10, corrections against the exact solution of the oracle's system,
+    the updated scene and its error; then one accepted LM iteration through the library's own loop with the same
+    attempt count and error as the oracle's loop."""
+    spec = sa.CONFIGS["C2_200cam_20kpt"]
+    sc = sa.config_scene("C2_200cam_20kpt")
+    assert (sc.M, sc.N, sc.O) == (200, 20000, 400000)
+    out = _phases(orc, gpu, sc, spec.f0, 1e-4)
+    _check(out, sc.M)
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, max_iterations=1)
+    assert not ok and rc_o == 1 and sa.status_string(rep.status) == "max iterations"
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts) and rep.iterations == 1
+    assert rep.err_initial == pytest.approx(rep_o.err_initial, rel=1e-12)
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+    assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+    assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
 
 
 # ------------------------------------------------------------------ full-size properties (no oracle at this size)

@@ -107,19 +107,54 @@ def _run(cmd, cwd):
     return json.loads(p.stdout.strip().splitlines()[-1]), p.stderr
 
 
+def _read_scene_dump(path, orc):
+    """demos/scene_dump.hpp: the flat scene a demo handed to (or got back from) ComputeInplace -> (f0, oracle scene)."""
+    raw = open(path, "rb").read()
+    N, M, O, shared = np.frombuffer(raw, dtype=np.int64, count=4)
+    off = 32
+    f0 = float(np.frombuffer(raw, dtype=np.float64, count=1, offset=off)[0])
+    off += 8
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=int(n), offset=off)
+        off += a.nbytes
+        return a
+    pts, R, T = take(np.float64, 3 * N), take(np.float64, 9 * M), take(np.float64, 3 * M)
+    K = take(np.float64, 9 * (1 if shared else M))
+    row_ptr, frames, uv = take(np.int64, N + 1), take(np.int32, O), take(np.float64, 2 * O)
+    assert off == len(raw)
+    return f0, orc.Scene(pts, R, T, K, int(shared), row_ptr, frames, uv)
+
+
 @pytest.mark.gpu
-def test_demo_circle_grid_cli_with_reference_flagfile(orc):
+def test_demo_circle_grid_cli_with_reference_flagfile(orc, tmp_path):
     """The C++ drop-in of demo-circle-grid with the reference's flagfile values (81 points x 36 frames, all visible,
-    rotation noise only) against the oracle run on the same scene built here in numpy."""
+    rotation noise only; cpp_impl/flagfile-demo-circle-grid.txt, call at demo-bundle-adj-circle-grid.cpp:285-293)
+    against the CPU oracle run on exactly the scene the demo handed to ComputeInplace: same result flag, status string,
+    iteration and attempt counts, error rel 1e-6, output scene abs 1e-6."""
     from conftest import ROOT
     exe = os.path.join(ROOT, "demos", "demo-circle-grid")
     if not os.path.exists(exe):
         pytest.skip("demos not built")
+    before, after = str(tmp_path / "before.bin"), str(tmp_path / "after.bin")
     out, log = _run([exe, "--flagfile=" + os.path.join(ROOT, "demos", "flagfile-demo-circle-grid.txt"),
-                     "--max_iterations=25"], ROOT)
+                     "--max_iterations=25", "--dump_scene_before=" + before, "--dump_scene_after=" + after], ROOT)
     assert out["frames"] == 36 and out["points"] == 81
-    assert out["iterations"] >= 1 and out["err_final"] < out["err_initial"]
     assert "bundle adjustment finished with result" in log
+    f0, so = _read_scene_dump(before, orc)
+    _, sg = _read_scene_dump(after, orc)
+    assert (f0, so.N, so.M, so.O, so.shared_k) == (600.0, 81, 36, 81 * 36, 0)
+    rc_o, rep_o = orc.compute_inplace(f0, so, 2.25e-12, None, 25)   # the flagfile's --allowed_repr_err
+    assert out["result"] == int(rc_o == 0)
+    assert out["status"] == orc.status_string(rep_o.status)
+    assert (out["iterations"], out["attempts"]) == (rep_o.iterations, rep_o.attempts)
+    assert out["err_initial"] == pytest.approx(rep_o.err_initial, rel=1e-12)
+    assert out["err_final"] == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+    assert out["iterations"] >= 1 and out["err_final"] < out["err_initial"]
+    assert np.abs(sg.points - so.points).max() < 1e-6
+    assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+    assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
 
 
 @pytest.mark.gpu
@@ -147,16 +182,33 @@ def test_demo_dino_cli(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_adapter_mvf_call_contract():
+def test_cpp_adapter_mvf_call_contract(orc, tmp_path):
     """the C++ mirror class in the multi-view-factorization call contract (shared K, f0 = 1,
-    threshold 1e-3, salient points created out of track order) equals the flat C-ABI call."""
+    threshold 1e-3, salient points created out of track order, one track without a salient point;
+    multi-view-factorization.cpp:379-394) against the CPU oracle on the scene the adapter flattened, and against the
+    flat C-ABI call."""
     from conftest import ROOT
     exe = os.path.join(ROOT, "demos", "test-adapter")
     if not os.path.exists(exe):
         pytest.skip("adapter test not built")
-    out, _ = _run([exe], ROOT)
+    before, after = str(tmp_path / "before.bin"), str(tmp_path / "after.bin")
+    out, _ = _run([exe, before, after], ROOT)
     assert out["ok"] == (out["rc"] == 0)
     assert out["seen"] == 42 * 5 and out["points"] == 42 and out["vars"] == 3 * 42 + 90 and out["normalized_vars"] == out["vars"] - 7
+    # the adapter against the oracle
+    f0, so = _read_scene_dump(before, orc)
+    _, sg = _read_scene_dump(after, orc)
+    assert (f0, so.N, so.M, so.O, so.shared_k) == (1.0, 42, 9, 210, 1)
+    e0, seen = orc.reproj_error(f0, so)
+    assert seen == out["seen"] and out["err0"] == pytest.approx(e0, rel=1e-12)
+    rc_o, rep_o = orc.compute_inplace(f0, so, 1e-3, None, 0)
+    assert out["ok"] == int(rc_o == 0) and out["status"] == orc.status_string(rep_o.status)
+    assert (out["iterations"], out["attempts"]) == (rep_o.iterations, rep_o.attempts)
+    assert out["err_final"] == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+    assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+    assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
+    # the adapter against the flat C ABI (same library underneath: must agree to rounding)
     assert out["err0"] == pytest.approx(out["err0_c"], rel=1e-12)
     assert out["iterations"] == out["iterations_c"]
     assert out["err_final"] == pytest.approx(out["err_final_c"], rel=1e-9)

@@ -2,10 +2,11 @@
 # development: rebuild libsrk_ba.so with one ablation macro at a time on the GPU box and time the Jacobian phase
 set -e
 cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
-cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
+# the variant is built to a temporary path and loaded through SRK_BA_LIBRARY: the product library stays untouched
+export SRK_BA_LIBRARY=/tmp/libsrk_ba_variant.so
 for abl in ${ABLS:-NONE}; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -D$abl -c srk_ba_kernels.hip -o /tmp/k_abl.o 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so /tmp/k_abl.o srk_chol.o srk_ba_host.o srk_scene.o srk_io.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -D$abl -c srk_ba_kernels.hip -o /tmp/k_abl.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$SRK_BA_LIBRARY" /tmp/k_abl.o srk_chol.o srk_ba_host.o srk_scene.o srk_io.o
   (cd "$GRAFT_REPO_ROOT" && python - <<PY
 import surikatoko_amd as sa, time
 spec=sa.CONFIGS["C3_1kcam_100kpt"]; sc=sa.generate_scene(spec)
@@ -17,4 +18,3 @@ print("$abl", (time.perf_counter()-t)/20*1e6, "us per derivatives phase (incl. m
 PY
 )
 done
-cp /tmp/libsrk_ba.so.orig ../libsrk_ba.so

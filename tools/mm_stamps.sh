@@ -2,9 +2,10 @@
 # development: in-kernel clock stamps of k_schur_mm (one multiplier and one helper lane of every workgroup) on the GPU box
 set -e
 cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
-cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DSRK_MM_STAMPS $EXTRA -c srk_ba_kernels.hip -o /tmp/k_st.o 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so /tmp/k_st.o srk_chol.o srk_ba_host.o srk_scene.o srk_io.o
+# the variant is built to a temporary path and loaded through SRK_BA_LIBRARY: the product library stays untouched
+export SRK_BA_LIBRARY=/tmp/libsrk_ba_variant.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DSRK_MM_STAMPS $EXTRA -c srk_ba_kernels.hip -o /tmp/k_st.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$SRK_BA_LIBRARY" /tmp/k_st.o srk_chol.o srk_ba_host.o srk_scene.o srk_io.o
 (cd "$GRAFT_REPO_ROOT" && python - <<'PY'
 import ctypes as C, numpy as np
 import surikatoko_amd as sa
@@ -29,4 +30,3 @@ for name,a in (("loader: stage",t[:,10]),("loader: Y of next round",t[:,13]),("l
 print("core clock over the workgroup: median %.2f GHz" % np.median(t[:,9]/(dur*10)))
 PY
 )
-cp /tmp/libsrk_ba.so.orig ../libsrk_ba.so

@@ -2,9 +2,10 @@
 # development: in-kernel clock stamps of k_panel (d = 40, last workgroup) on the GPU box
 set -e
 cd "$GRAFT_REPO_ROOT/surikatoko_amd/csrc"
-cp ../libsrk_ba.so /tmp/libsrk_ba.so.orig
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DSRK_PANEL_STAMPS -c srk_chol.hip -o /tmp/chol_st.o 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsrk_ba.so srk_ba_kernels.o /tmp/chol_st.o srk_ba_host.o srk_scene.o srk_io.o
+# the variant is built to a temporary path and loaded through SRK_BA_LIBRARY: the product library stays untouched
+export SRK_BA_LIBRARY=/tmp/libsrk_ba_variant.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DSRK_PANEL_STAMPS -c srk_chol.hip -o /tmp/chol_st.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$SRK_BA_LIBRARY" srk_ba_kernels.o /tmp/chol_st.o srk_ba_host.o srk_scene.o srk_io.o
 (cd "$GRAFT_REPO_ROOT" && python - <<'PY'
 import ctypes as C, numpy as np
 import surikatoko_amd as sa
@@ -22,4 +23,3 @@ print("  sweep quarters:", out[7]-out[4], out[8]-out[7], out[9]-out[8], out[5]-o
 print("  total", (t[-1]-t[0])*10/1000, "us")
 PY
 )
-cp /tmp/libsrk_ba.so.orig ../libsrk_ba.so
