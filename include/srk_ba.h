@@ -225,6 +225,14 @@ double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates o
  * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time. */
 int srk_ba_set_speculation(srk_ba*, int on);
 
+/* Derivative kernel selection (harness knob, the reference has one code path: bundle-adj-kanatani.cpp:1140-1448).
+ * mode -1 = automatic: the run-based kernel (a lane keeps one frame's sums in registers over a run of landmarks with
+ * identical frame lists) when the runs are long enough, else the per-observation kernels; 0 = per-observation kernels
+ * only; 1 = run-based whenever the scene allows it (tracks of <= 64 frames, narrow frame windows).  Takes effect at the next upload.  srk_ba_jacobian_kernel: 2 = run-based, 1 = fused per-observation,
+ * 0 = two-kernel path, -1 = no scene. */
+int srk_ba_set_jacobian_mode(srk_ba*, int mode);
+int srk_ba_jacobian_kernel(srk_ba*);
+
 /* Opt-in mixed precision for the reduced camera system (the reference's suriko_scalar_type_string = f32 switch,
  * suriko-engine/CMakeLists.txt:14-15, applied where it pays on this hardware): fp32 = 1 rounds W and E^-1 W to fp32
  * when they are staged and accumulates each run of <= 128 landmarks with packed fp32 FMAs; the runs' sums, the frame

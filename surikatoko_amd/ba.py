@@ -281,6 +281,13 @@ class BundleAdjustmentKanatani:
         """Run the next damping factor beside the current attempt (one rank, instrumentation off); next upload."""
         self._raise(self._lib.srk_ba_set_speculation(C.c_void_p(self._h), C.c_int(int(bool(on)))))
 
+    def set_jacobian_mode(self, mode=-1):
+        """-1 automatic, 0 = per-observation kernels only, 1 = run-based whenever possible (next upload)"""
+        self._raise(self._lib.srk_ba_set_jacobian_mode(C.c_void_p(self._h), C.c_int(mode)))
+
+    def jacobian_kernel(self):
+        return int(self._lib.srk_ba_jacobian_kernel(C.c_void_p(self._h)))
+
     def set_schur_precision(self, fp32=False):
         """Opt-in mixed precision: fp32 run sums in the grouped Schur kernel (everything else stays fp64)."""
         self._raise(self._lib.srk_ba_set_schur_precision(C.c_void_p(self._h), C.c_int(int(bool(fp32)))))

@@ -55,6 +55,11 @@ struct srk_ba {
     DevBuf sc_pts, sc_R, sc_T, sc_K, sc_cam, sc_frame, sc_pt, sc_uv, sc_partial, sc_out; // standalone scoring path
     int64_t n_groups = 0, n_groups_wide = 0, n_groups_mid = 0, n_generic = 0;
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
+    // run-based Jacobian kernel (k_jac_runs): tasks = pieces of runs of landmarks with identical frame lists
+    DevBuf jr_first, jr_count, jr_jmin;
+    int32_t jr_tasks = 0;
+    bool jac_runs = false;  // the tasks are long enough to pay and every workgroup's frame window fits
+    int jac_mode = -1;      // -1 = automatic, 0 = never k_jac_runs, 1 = whenever possible (srk_ba_set_jacobian_mode)
     // skyline of the reduced camera system (see k_env_zero): host + device copies
     std::vector<int32_t> min_cv;                       // [M] smallest frame sharing a landmark with frame j
     std::vector<int64_t> env_col_h, env_off_h, row_end_h, col_begin_h;
@@ -206,7 +211,8 @@ void srk_ba_destroy(srk_ba* h)
                       &h->camT[2], &h->K, &h->cam[0], &h->cam[1], &h->cam[2], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
-                      &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off };
+                      &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off,
+                      &h->jr_first, &h->jr_count, &h->jr_jmin };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
         for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed }) dev_free(*b);
@@ -738,6 +744,41 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         wg_jmin.push_back(lo);
     }
 
+    // tasks of the run-based Jacobian kernel: maximal runs of consecutive landmarks (internal order) with identical
+    // frame lists, cut into pieces of <= SRK_JR_TASK_PTS_HOST landmarks (a multiple of the landmarks per iteration)
+    std::vector<int32_t> jr_first, jr_count, jr_jmin;
+    h->jac_runs = h->jac_mode != 0;
+    for (int64_t i = 0; i < N && h->jac_runs;) {
+        const int64_t nf = rp[(size_t)i + 1] - rp[(size_t)i];
+        if (nf == 0) { ++i; continue; }
+        if (nf > 64) { h->jac_runs = false; break; }
+        int64_t j = i + 1;
+        while (j < N && rp[(size_t)j + 1] - rp[(size_t)j] == nf &&
+               std::equal(of.begin() + rp[(size_t)i], of.begin() + rp[(size_t)i + 1], of.begin() + rp[(size_t)j])) ++j;
+        const int64_t g = 64 / nf, len = j - i;
+        const int64_t pieces = (len + SRK_JR_TASK_PTS_HOST - 1) / SRK_JR_TASK_PTS_HOST;
+        const int64_t piece = std::max<int64_t>(g, ((len + pieces - 1) / pieces + g - 1) / g * g);
+        for (int64_t a = i; a < j; a += piece) {
+            jr_first.push_back((int32_t)a);
+            jr_count.push_back((int32_t)std::min<int64_t>(piece, j - a));
+        }
+        i = j;
+    }
+    if (h->jac_runs) {
+        // long enough to pay: a task flushes 65 sums per lane, which an iteration of the per-observation kernel costs
+        if (jr_first.empty() || (h->jac_mode != 1 && O / (int64_t)jr_first.size() < 256)) h->jac_runs = false;
+        for (size_t t0 = 0; t0 < jr_first.size() && h->jac_runs; t0 += 4) {
+            int32_t lo = M, hi = -1;
+            for (size_t t = t0; t < std::min(jr_first.size(), t0 + 4); ++t) {
+                const int64_t a = rp[(size_t)jr_first[t]], b = rp[(size_t)jr_first[t] + 1];
+                lo = std::min(lo, of[(size_t)a]);
+                hi = std::max(hi, of[(size_t)b - 1]);
+            }
+            if (hi - lo >= SRK_JF_SLOTS_HOST) h->jac_runs = false;
+            jr_jmin.push_back(lo);
+        }
+    }
+    h->jr_tasks = h->jac_runs ? (int32_t)jr_first.size() : 0;
 
 #define ALLOC(buf, bytes)                              \
     do {                                               \
@@ -789,6 +830,11 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->pt_mask, 4 * pt_mask.size());
     ALLOC(h->gen_list, 4 * gen_list.size());
     ALLOC(h->wg_jmin, 4 * wg_jmin.size());
+    if (h->jac_runs) {
+        ALLOC(h->jr_first, 4 * jr_first.size());
+        ALLOC(h->jr_count, 4 * jr_count.size());
+        ALLOC(h->jr_jmin, 4 * jr_jmin.size());
+    }
 #undef ALLOC
     hipStream_t s = h->stream;
 #define H2D(buf, src, bytes)                                                                               \
@@ -817,6 +863,11 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->pt_mask, pt_mask.data(), 4 * pt_mask.size());
     H2D(h->gen_list, gen_list.data(), 4 * gen_list.size());
     H2D(h->wg_jmin, wg_jmin.data(), 4 * wg_jmin.size());
+    if (h->jac_runs) {
+        H2D(h->jr_first, jr_first.data(), 4 * jr_first.size());
+        H2D(h->jr_count, jr_count.data(), 4 * jr_count.size());
+        H2D(h->jr_jmin, jr_jmin.data(), 4 * jr_jmin.size());
+    }
 #undef H2D
     for (auto& a : h->att) {
         if (!a.allocated) continue;
@@ -951,7 +1002,12 @@ static int phase_derivatives(srk_ba* h)
     HIPCHK(h, hipMemsetAsync(h->Vg.p, 0, 8 * 9 * d.Ns, s));
     HIPCHK(h, hipMemsetAsync(h->Ug.p, 0, 8 * SRK_UG * (int64_t)d.M, s));
     if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[12], s));
-    if (h->jac_fused) {
+    if (h->jac_runs) {
+        srk_launch_jac_runs(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame),
+                            P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg), P<double>(h->Ug), P<int32_t>(h->jr_first),
+                            P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin));
+        if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
+    } else if (h->jac_fused) {
         srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
                              P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg),
                              P<double>(h->Ug), P<int32_t>(h->wg_jmin));
@@ -1889,6 +1945,16 @@ int srk_ba_set_speculation(srk_ba* h, int on)
     h->speculate = on != 0; // takes effect at the next upload (the second attempt slot is allocated there)
     return SRK_OK;
 }
+
+// -1 = automatic (run-based kernel when the runs of identical frame lists are long enough), 0 = per-observation kernels
+// only, 1 = run-based whenever the scene allows it; takes effect at the next upload.  For A/B runs and for the parity tests of both kernels on the same scene.
+int srk_ba_set_jacobian_mode(srk_ba* h, int mode)
+{
+    if (!h || mode < -1 || mode > 1) return SRK_E_ARGS;
+    h->jac_mode = mode;
+    return SRK_OK;
+}
+int srk_ba_jacobian_kernel(srk_ba* h) { return (h && h->have_scene) ? (h->jac_runs ? 2 : (h->jac_fused ? 1 : 0)) : -1; }
 
 int srk_ba_set_schur_precision(srk_ba* h, int fp32)
 {

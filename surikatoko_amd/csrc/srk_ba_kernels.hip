@@ -367,6 +367,188 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
                        Vg, Ug, wg_jmin);
 }
 
+// ------------------------------------------------------------------ K2 by runs: a lane keeps ONE frame for a whole task
+// Landmarks are stored sorted by frame list, so landmarks with IDENTICAL lists form runs.  A task = up to
+// SRK_JR_TASK_PTS consecutive landmarks of one run (nf frames each); one wave per task.  Lane l works on frame
+// f = l % nf of landmark m = l / nf of the current iteration (g = 64 / nf landmarks per iteration, g nf <= 64 active
+// lanes), so across the task's iterations a lane stays on ONE frame:
+//   * the 55 + 10 frame-block / frame-gradient sums live in the lane's registers and go to the workgroup's LDS slot of
+//     that frame once per task (k_jac_fused: 65 LDS atomics per OBSERVATION);
+//   * a landmark's nf observations all sit in one iteration of one wave: its point block and gradient are summed in
+//     a fixed order from a per-wave LDS scratch and stored plainly (no atomics, no 64-lane segmented scan);
+//   * the W stores stay lane-contiguous (observations o_base + it g nf + lane).
+// The host uses this kernel when the tasks are long enough to pay (circle-grid scenes: ~100 landmarks per run).
+#define SRK_JR_RSTRIDE 66 // doubles between the 9 planes of the per-wave reduction scratch (64 lanes + bank skew)
+
+__global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __restrict__ pts,
+                                                     const double* __restrict__ cam,
+                                                     const int64_t* __restrict__ row_ptr,
+                                                     const int32_t* __restrict__ obs_frame,
+                                                     const double* __restrict__ obs_uv, double* __restrict__ W,
+                                                     double* __restrict__ Vg, double* __restrict__ Ug,
+                                                     const int32_t* __restrict__ task_first,
+                                                     const int32_t* __restrict__ task_count, int32_t n_tasks,
+                                                     const int32_t* __restrict__ wg_jmin)
+{
+    __shared__ double sU[SRK_JF_SLOTS][SRK_UG + 1];                                  // frame blocks + frame gradients
+    __shared__ __attribute__((aligned(16))) double sCam[SRK_JF_SLOTS][SRK_CAM_PACK]; // camera packs of the frame window
+    __shared__ double sR[4][9 * SRK_JR_RSTRIDE];                                     // per-wave landmark reduction
+    __shared__ int sTouched[SRK_JF_SLOTS];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int jmin = wg_jmin[blockIdx.x];
+    for (int t = threadIdx.x; t < SRK_JF_SLOTS * (SRK_UG + 1); t += 256) (&sU[0][0])[t] = 0.0;
+    if (threadIdx.x < SRK_JF_SLOTS) sTouched[threadIdx.x] = 0;
+    {
+        int nfr = d.M - jmin < SRK_JF_SLOTS ? d.M - jmin : SRK_JF_SLOTS;
+        const double* src = cam + (int64_t)SRK_CAM_PACK * jmin;
+        for (int t = threadIdx.x; t < nfr * SRK_CAM_PACK; t += 256) (&sCam[0][0])[t] = src[t];
+    }
+    __syncthreads();
+    const int task = blockIdx.x * 4 + wv;
+    if (task < n_tasks) {
+        const int32_t first_pt = task_first[task], n_pts = task_count[task];
+        const int64_t o_base = row_ptr[first_pt];
+        const int nf = (int)(row_ptr[first_pt + 1] - o_base);
+        const int g = WAVE / nf, active = g * nf;
+        const int m = lane / nf, f = lane - m * nf;
+        const bool on = lane < active;
+        const int js = on ? obs_frame[o_base + f] - jmin : 0;
+        const double* c = sCam[js];
+        double* sr = sR[wv];
+        double acc[SRK_UG];
+#pragma unroll
+        for (int k = 0; k < SRK_UG; ++k) acc[k] = 0;
+        // software pipeline: the next iteration's observation and landmark are loaded while this one is computed
+        double2 uv_n = make_double2(0, 0);
+        double Xn0 = 0, Xn1 = 0, Xn2 = 0;
+        if (on && m < n_pts) {
+            uv_n = reinterpret_cast<const double2*>(obs_uv)[o_base + (int64_t)m * nf + f];
+            const double* X = pts + 3 * (int64_t)(first_pt + m);
+            Xn0 = X[0]; Xn1 = X[1]; Xn2 = X[2];
+        }
+#pragma unroll 1
+        for (int i0 = 0; i0 < n_pts; i0 += g) {
+            const int il = i0 + m;
+            const bool valid = on && il < n_pts;
+            const int64_t o = o_base + (int64_t)il * nf + f;
+            const double2 uv = uv_n;
+            const double X0 = Xn0, X1 = Xn1, X2 = Xn2;
+            if (on && il + g < n_pts) {
+                uv_n = reinterpret_cast<const double2*>(obs_uv)[o + (int64_t)g * nf];
+                const double* X = pts + 3 * (int64_t)(first_pt + il + g);
+                Xn0 = X[0]; Xn1 = X[1]; Xn2 = X[2];
+            }
+            double v9[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v9[k] = 0;
+            if (valid) {
+                // (p, q, r) = K (R X + T)   (:469-470)
+                const double xc0 = c[0] * X0 + c[1] * X1 + c[2] * X2 + c[9];
+                const double xc1 = c[3] * X0 + c[4] * X1 + c[5] * X2 + c[10];
+                const double xc2 = c[6] * X0 + c[7] * X1 + c[8] * X2 + c[11];
+                const double p = c[12] * xc0 + c[13] * xc1 + c[14] * xc2;
+                const double q = c[15] * xc0 + c[16] * xc1 + c[17] * xc2;
+                const double r = c[18] * xc0 + c[19] * xc1 + c[20] * xc2;
+                const double ir = jf_rcp(r), ir2 = ir * ir;
+                // Every entry is (2 / r^4) (A A' + B B') (formula 9) or (2 / r^2) (ex A + ey B) (formula 8): with the
+                // A's and B's scaled by sqrt(2) / r^2 once, the blocks are plain products and the gradient terms carry
+                // sqrt(2) ex, sqrt(2) ey (no second, pre-scaled copy of the 26 values: they would not fit the registers
+                // beside the 65 frame sums).
+                const double sc = 1.4142135623730951 * ir2;
+                const double exs = (p * ir - uv.x * c[46]) * 1.4142135623730951, eys = (q * ir - uv.y * c[46]) * 1.4142135623730951;
+                const double rs = r * sc, ps = p * sc, qs = q * sc;
+                double Ap[3], Bp[3], Af[10], Bf[10];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    Ap[v] = rs * c[21 + v] - ps * c[27 + v];
+                    Bp[v] = rs * c[24 + v] - qs * c[27 + v];
+                }
+                const double g_uv = c[46] * r * rs;
+                Af[0] = rs * (c[42] * p - c[43] * r); Bf[0] = 0;
+                Af[1] = 0;                            Bf[1] = rs * (c[44] * q - c[45] * r);
+                Af[2] = g_uv;                         Bf[2] = 0;
+                Af[3] = 0;                            Bf[3] = g_uv;
+                // translation and rotation columns share a1 = r rot1 - p rot3, b1 = r rot2 - q rot3 :
+                //   d/dT = -(a1, b1)   (:1503-1505)      d/dW = (a1 x t, b1 x t), t = X - T_direct   (:1511-1520)
+                double a1[3], b1[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    a1[k] = rs * c[33 + k] - ps * c[39 + k];
+                    b1[k] = rs * c[36 + k] - qs * c[39 + k];
+                    Af[4 + k] = -a1[k];
+                    Bf[4 + k] = -b1[k];
+                }
+                const double t0 = X0 - c[30], t1 = X1 - c[31], t2 = X2 - c[32];
+                Af[7] = a1[1] * t2 - a1[2] * t1; Af[8] = a1[2] * t0 - a1[0] * t2; Af[9] = a1[0] * t1 - a1[1] * t0;
+                Bf[7] = b1[1] * t2 - b1[2] * t1; Bf[8] = b1[2] * t0 - b1[0] * t2; Bf[9] = b1[0] * t1 - b1[1] * t0;
+                double* wp = W + o;
+#pragma unroll
+                for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+                    for (int fv = 0; fv < 10; ++fv) {
+                        *wp = Ap[pv] * Af[fv] + Bp[pv] * Bf[fv];
+                        wp += d.Os;
+                    }
+                v9[0] = Ap[0] * Ap[0] + Bp[0] * Bp[0];
+                v9[1] = Ap[0] * Ap[1] + Bp[0] * Bp[1];
+                v9[2] = Ap[0] * Ap[2] + Bp[0] * Bp[2];
+                v9[3] = Ap[1] * Ap[1] + Bp[1] * Bp[1];
+                v9[4] = Ap[1] * Ap[2] + Bp[1] * Bp[2];
+                v9[5] = Ap[2] * Ap[2] + Bp[2] * Bp[2];
+                v9[6] = exs * Ap[0] + eys * Bp[0];
+                v9[7] = exs * Ap[1] + eys * Bp[1];
+                v9[8] = exs * Ap[2] + eys * Bp[2];
+                int idx = 0;
+#pragma unroll
+                for (int v1 = 0; v1 < 10; ++v1)
+#pragma unroll
+                    for (int v2 = v1; v2 < 10; ++v2) {
+                        acc[idx] += Af[v1] * Af[v2] + Bf[v1] * Bf[v2];
+                        ++idx;
+                    }
+#pragma unroll
+                for (int v = 0; v < 10; ++v) acc[55 + v] += exs * Af[v] + eys * Bf[v];
+            }
+            // point block + gradient of the g landmarks of this iteration: every lane parks its nine terms in the wave's
+            // scratch, lane (k, mm) adds landmark mm's nf terms of entry k in frame order and stores the sum.  LDS
+            // operations of one wave execute in order: no barrier, the waits only keep the compiler from reordering.
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sr[k * SRK_JR_RSTRIDE + lane] = v9[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int rr = lane; rr < 9 * g; rr += WAVE) {
+                const int k = rr / g, mm = rr - k * g;
+                if (i0 + mm < n_pts) {
+                    const double* src = sr + k * SRK_JR_RSTRIDE + mm * nf;
+                    double sum = 0;
+                    for (int ff = 0; ff < nf; ++ff) sum += src[ff];
+                    Vg[(int64_t)k * d.Ns + first_pt + i0 + mm] = sum;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (on) {
+            double* su = sU[js];
+            sTouched[js] = 1;
+#pragma unroll
+            for (int k = 0; k < SRK_UG; ++k) atomicAdd(&su[k], acc[k]);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SRK_JF_SLOTS * SRK_UG; t += 256) {
+        int slot = t / SRK_UG, k = t - slot * SRK_UG;
+        if (sTouched[slot]) atomicAdd(&Ug[(int64_t)(jmin + slot) * SRK_UG + k], sU[slot][k]);
+    }
+}
+
+void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, const double* cam, const int64_t* row_ptr,
+                         const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
+                         const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin)
+{
+    if (n_tasks <= 0) return;
+    hipLaunchKernelGGL(k_jac_runs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame,
+                       obs_uv, W, Vg, Ug, task_first, task_count, n_tasks, wg_jmin);
+}
+
 void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                            const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
                            double* Vg)

@@ -179,6 +179,80 @@ def test_phases_on_synthetic_scenes(orc, gpu, name, c):
     _check(out, sc.M, corr_tol=1e-7)
 
 
+# ------------------------------------------------------------------ the run-based derivative kernel (k_jac_runs)
+
+JAC_RUN_SCENES = {
+    # one wave per task of <= 36 landmarks with identical frame lists; 64 // nf landmarks per iteration
+    "nf20": sa.SceneSpec(n_frames=30, grid_nx=33, grid_ny=31, vis_window=20),       # 3 landmarks / iteration, 60 active lanes
+    "nf16": sa.SceneSpec(n_frames=24, grid_nx=30, grid_ny=20, vis_window=16),       # 4 / iteration, every lane active
+    "nf13": sa.SceneSpec(n_frames=15, grid_nx=17, grid_ny=13, vis_window=13),       # 4 / iteration, 52 lanes
+    "nf3_many_per_iteration": sa.SceneSpec(n_frames=12, grid_nx=25, grid_ny=20, vis_window=3),  # 21 / iteration: 189 sums in 3 passes
+    "nf2": sa.SceneSpec(n_frames=6, grid_nx=9, grid_ny=7, vis_window=2),            # 32 / iteration
+    "nf40_one_per_iteration": sa.SceneSpec(n_frames=44, grid_nx=12, grid_ny=10, vis_window=40),
+    "all_visible_nf8": sa.SceneSpec(n_frames=8, grid_nx=9, grid_ny=9, vis_window=0),  # one run of 81 landmarks
+    "pixel_noise": sa.SceneSpec(n_frames=12, grid_nx=10, grid_ny=10, vis_window=5, noise_uv_pix=0.5),
+}
+
+
+@pytest.mark.parametrize("name", list(JAC_RUN_SCENES))
+def test_run_based_derivative_kernel_vs_oracle(orc, gpu, name):
+    """k_jac_runs (a lane keeps one frame's 65 sums in registers over a task; landmark sums in a fixed order through a
+    per-wave scratch) forced on small scenes: blocks rel 1e-12, gradient rel 1e-10 against the oracle, and the whole
+    chain behind it (bundle-adj-kanatani.cpp:1140-1448)."""
+    spec = JAC_RUN_SCENES[name]
+    sc = sa.generate_scene(spec)
+    gpu.set_jacobian_mode(1)
+    try:
+        out = _phases(orc, gpu, sc, spec.f0, 1e-4)
+        assert gpu.jacobian_kernel() == 2
+        _check(out, sc.M, corr_tol=1e-7)
+    finally:
+        gpu.set_jacobian_mode(-1)
+
+
+def test_run_based_derivative_kernel_on_golden_inputs_and_ragged_tracks(orc, gpu):
+    """The prototype's golden blocks through k_jac_runs; and ragged tracks (every landmark a run of its own: tasks of
+    one landmark) still give the oracle's blocks."""
+    gpu.set_jacobian_mode(1)
+    try:
+        for case in ("pyproto_case_a", "pyproto_case_b"):
+            sc, f0, g = _golden_scene(case)
+            out = _phases(orc, gpu, sc, f0, 1e-1)
+            assert gpu.jacobian_kernel() == 2
+            _check(out, sc.M, corr_tol=1e-8)
+            N, M = sc.N, sc.M
+            assert rel_err(out["V_g"].reshape(3 * N, 3), g["deriv_second_point"]) < 1e-12
+            assert rel_err(out["U_g"].reshape(10 * M, 10), g["deriv_second_frame"]) < 1e-12
+            assert rel_err(out["gradE_g"], g["gradE"]) < 1e-10
+        spec = sa.SceneSpec(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7)
+        sc = sa.drop_observations(sa.generate_scene(spec), 0.25, seed=3)
+        out = _phases(orc, gpu, sc, spec.f0, 1e-4)
+        assert gpu.jacobian_kernel() == 2
+        _check(out, sc.M, corr_tol=1e-7)
+    finally:
+        gpu.set_jacobian_mode(-1)
+
+
+def test_derivative_kernels_agree_at_bench_size(gpu):
+    """BASELINE config 3 (the bench workload): the run-based kernel (picked automatically there) and the per-observation
+    fused kernel give the same blocks to rounding (different summation orders), landmark by landmark."""
+    spec = sa.CONFIGS["C3_1kcam_100kpt"]
+    sc = sa.config_scene("C3_1kcam_100kpt")
+    res = {}
+    try:
+        for mode in (-1, 0):
+            gpu.set_jacobian_mode(mode)
+            assert gpu.upload(spec.f0, sc)
+            assert gpu.jacobian_kernel() == (2 if mode == -1 else 1)
+            gpu.phase_derivatives()
+            res[mode] = (gpu.buffer(B.BUF_GRAD).copy(), gpu.buffer(B.BUF_POINT_BLOCKS).copy(),
+                         gpu.buffer(B.BUF_FRAME_BLOCKS).copy(), gpu.buffer(B.BUF_POINT_FRAME)[::97].copy())
+    finally:
+        gpu.set_jacobian_mode(-1)
+    for a, b, tol in zip(res[-1], res[0], (1e-10, 1e-12, 1e-11, 1e-12)):
+        assert rel_err(a, b) < tol
+
+
 MFMA_EDGES = {
     # k_schur_mm sums a run as a (10 nf) x (10 nf) x (3 np) fp64 MFMA product over 16x16 tiles and rounds of four
     # landmarks: frame counts whose 10 nf is / is not a multiple of 16, runs that are not a multiple of four landmarks
