@@ -57,7 +57,7 @@ struct srk_ba {
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // run-based Jacobian kernel (k_jac_runs): tasks = pieces of runs of landmarks with identical frame lists
     DevBuf jr_first, jr_count, jr_jmin;
-    int32_t jr_tasks = 0;
+    int32_t jr_tasks = 0, jr_min_nf = 64;
     bool jac_runs = false;  // the tasks are long enough to pay and every workgroup's frame window fits
     int jac_mode = -1;      // -1 = automatic, 0 = never k_jac_runs, 1 = whenever possible (srk_ba_set_jacobian_mode)
     // skyline of the reduced camera system (see k_env_zero): host + device copies
@@ -745,18 +745,35 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     }
 
     // tasks of the run-based Jacobian kernel: maximal runs of consecutive landmarks (internal order) with identical
-    // frame lists, cut into pieces of <= SRK_JR_TASK_PTS_HOST landmarks (a multiple of the landmarks per iteration)
+    // frame lists, cut into pieces (a multiple of the landmarks per step).  The kernel holds two 4-wave workgroups per
+    // CU (a wave keeps 61 frame sums and a step of look-ahead in ~250 registers); with about one task per wave slot
+    // every task runs at the same time and the stores of all of them share HBM from start to end (with 1.4 rounds of
+    // shorter tasks the second round ran at 2 TB/s).
     std::vector<int32_t> jr_first, jr_count, jr_jmin;
-    h->jac_runs = h->jac_mode != 0;
+    // (the kernel addresses W with 32-bit byte offsets inside a plane and inside each half of the 30 planes)
+    h->jac_runs = h->jac_mode != 0 && O < (int64_t)1 << 27;
+    h->jr_min_nf = 64;
+    int64_t jr_piece_target = SRK_JR_TASK_PTS_MIN_HOST;
+    {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        int64_t with_obs = 0;
+        for (int64_t i = 0; i < N; ++i) with_obs += rp[(size_t)i + 1] > rp[(size_t)i];
+        const int64_t slots = 8 * (int64_t)cus; // waves resident at once
+        jr_piece_target = std::min<int64_t>(SRK_JR_TASK_PTS_MAX_HOST, std::max<int64_t>(SRK_JR_TASK_PTS_MIN_HOST, (with_obs + slots - 1) / slots));
+    }
     for (int64_t i = 0; i < N && h->jac_runs;) {
         const int64_t nf = rp[(size_t)i + 1] - rp[(size_t)i];
         if (nf == 0) { ++i; continue; }
         if (nf > 64) { h->jac_runs = false; break; }
+        h->jr_min_nf = std::min<int32_t>(h->jr_min_nf, (int32_t)nf);
         int64_t j = i + 1;
         while (j < N && rp[(size_t)j + 1] - rp[(size_t)j] == nf &&
                std::equal(of.begin() + rp[(size_t)i], of.begin() + rp[(size_t)i + 1], of.begin() + rp[(size_t)j])) ++j;
         const int64_t g = 64 / nf, len = j - i;
-        const int64_t pieces = (len + SRK_JR_TASK_PTS_HOST - 1) / SRK_JR_TASK_PTS_HOST;
+        const int64_t most = SRK_JR_TASK_PTS_MAX_HOST / g * g; // the kernel stages a task's landmarks in LDS
+        const int64_t pieces = std::max<int64_t>((len + most - 1) / most, (len + jr_piece_target / 2) / jr_piece_target);
         const int64_t piece = std::max<int64_t>(g, ((len + pieces - 1) / pieces + g - 1) / g * g);
         for (int64_t a = i; a < j; a += piece) {
             jr_first.push_back((int32_t)a);
@@ -1005,7 +1022,7 @@ static int phase_derivatives(srk_ba* h)
     if (h->jac_runs) {
         srk_launch_jac_runs(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame),
                             P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg), P<double>(h->Ug), P<int32_t>(h->jr_first),
-                            P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin));
+                            P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin), h->jr_min_nf);
         if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
     } else if (h->jac_fused) {
         srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),

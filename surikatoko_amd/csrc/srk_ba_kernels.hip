@@ -368,8 +368,8 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
 }
 
 // ------------------------------------------------------------------ K2 by runs: a lane keeps ONE frame for a whole task
-// Landmarks are stored sorted by frame list, so landmarks with IDENTICAL lists form runs.  A task = up to
-// SRK_JR_TASK_PTS consecutive landmarks of one run (nf frames each); one wave per task.  Lane l works on frame
+// Landmarks are stored sorted by frame list, so landmarks with IDENTICAL lists form runs.  A task = a piece of one
+// run (nf frames each; the host sizes the pieces so that about one task per resident wave exists); one wave per task.  Lane l works on frame
 // f = l % nf of landmark m = l / nf of the current iteration (g = 64 / nf landmarks per iteration, g nf <= 64 active
 // lanes), so across the task's iterations a lane stays on ONE frame:
 //   * the 55 + 10 frame-block / frame-gradient sums live in the lane's registers and go to the workgroup's LDS slot of
@@ -378,6 +378,16 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
 //     a fixed order from a per-wave LDS scratch and stored plainly (no atomics, no 64-lane segmented scan);
 //   * the W stores stay lane-contiguous (observations o_base + it g nf + lane).
 // The host uses this kernel when the tasks are long enough to pay (circle-grid scenes: ~100 landmarks per run).
+// Measured on C3 (2 M observations, 20 frames a landmark): 119 us a launch against 178 us for k_jac_fused; without the
+// W stores it takes 57 us, the stores alone 87 us -- what is left is overlap between the two at two waves per SIMD
+// (61 frame sums + 26 derivative values = 230 registers).  Tried and dropped (round 2, each measured): W stored from a
+// second, 64-aligned walk over the observations (whole 512-byte rows instead of 60-lane rows that start off a line
+// boundary; the derivatives formed twice): 123 us; the same as straight-line code with buffer stores (masked lanes
+// dropped by the range check) so that the compiler counts the stores behind a load instead of waiting with vmcnt(0):
+// 177 us at two waves per SIMD, 194 us at one -- like the ablation without the frame sums (161 us), every variant that
+// lets the waves issue their stores FASTER ran slower, the 60 k concurrent 512-byte write streams (2048 waves x 30
+// planes) evidently need the pacing; non-temporal stores: +40 us; the four waves of a workgroup interleaved over one
+// task (neighbouring pieces written together): +5 us.
 #define SRK_JR_RSTRIDE 66 // doubles between the 9 planes of the per-wave reduction scratch (64 lanes + bank skew)
 
 __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __restrict__ pts,
@@ -404,7 +414,9 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
         for (int t = threadIdx.x; t < nfr * SRK_CAM_PACK; t += 256) (&sCam[0][0])[t] = src[t];
     }
     __syncthreads();
+    {
     const int task = blockIdx.x * 4 + wv;
+    const int step_first = 0, step_stride = 1;
     if (task < n_tasks) {
         const int32_t first_pt = task_first[task], n_pts = task_count[task];
         const int64_t o_base = row_ptr[first_pt];
@@ -421,21 +433,21 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
         // software pipeline: the next iteration's observation and landmark are loaded while this one is computed
         double2 uv_n = make_double2(0, 0);
         double Xn0 = 0, Xn1 = 0, Xn2 = 0;
-        if (on && m < n_pts) {
-            uv_n = reinterpret_cast<const double2*>(obs_uv)[o_base + (int64_t)m * nf + f];
-            const double* X = pts + 3 * (int64_t)(first_pt + m);
+        if (on && step_first * g + m < n_pts) {
+            uv_n = reinterpret_cast<const double2*>(obs_uv)[o_base + (int64_t)(step_first * g + m) * nf + f];
+            const double* X = pts + 3 * (int64_t)(first_pt + step_first * g + m);
             Xn0 = X[0]; Xn1 = X[1]; Xn2 = X[2];
         }
 #pragma unroll 1
-        for (int i0 = 0; i0 < n_pts; i0 += g) {
+        for (int i0 = step_first * g; i0 < n_pts; i0 += step_stride * g) {
             const int il = i0 + m;
             const bool valid = on && il < n_pts;
             const int64_t o = o_base + (int64_t)il * nf + f;
             const double2 uv = uv_n;
             const double X0 = Xn0, X1 = Xn1, X2 = Xn2;
-            if (on && il + g < n_pts) {
-                uv_n = reinterpret_cast<const double2*>(obs_uv)[o + (int64_t)g * nf];
-                const double* X = pts + 3 * (int64_t)(first_pt + il + g);
+            if (on && il + step_stride * g < n_pts) {
+                uv_n = reinterpret_cast<const double2*>(obs_uv)[o + (int64_t)step_stride * g * nf];
+                const double* X = pts + 3 * (int64_t)(first_pt + il + step_stride * g);
                 Xn0 = X[0]; Xn1 = X[1]; Xn2 = X[2];
             }
             double v9[9];
@@ -503,28 +515,36 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                 for (int v1 = 0; v1 < 10; ++v1)
 #pragma unroll
                     for (int v2 = v1; v2 < 10; ++v2) {
-                        acc[idx] += Af[v1] * Af[v2] + Bf[v1] * Bf[v2];
+                        acc[idx] = fma(Af[v1], Af[v2], fma(Bf[v1], Bf[v2], acc[idx]));
                         ++idx;
                     }
 #pragma unroll
-                for (int v = 0; v < 10; ++v) acc[55 + v] += exs * Af[v] + eys * Bf[v];
+                for (int v = 0; v < 10; ++v) acc[55 + v] = fma(exs, Af[v], fma(eys, Bf[v], acc[55 + v]));
             }
             // point block + gradient of the g landmarks of this iteration: every lane parks its nine terms in the wave's
             // scratch, lane (k, mm) adds landmark mm's nf terms of entry k in frame order and stores the sum.  LDS
-            // operations of one wave execute in order: no barrier, the waits only keep the compiler from reordering.
+            // operations of one wave execute in order: no barrier and no wait, only the compiler must keep the order.
 #pragma unroll
             for (int k = 0; k < 9; ++k) sr[k * SRK_JR_RSTRIDE + lane] = v9[k];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
             for (int rr = lane; rr < 9 * g; rr += WAVE) {
                 const int k = rr / g, mm = rr - k * g;
                 if (i0 + mm < n_pts) {
                     const double* src = sr + k * SRK_JR_RSTRIDE + mm * nf;
-                    double sum = 0;
-                    for (int ff = 0; ff < nf; ++ff) sum += src[ff];
-                    Vg[(int64_t)k * d.Ns + first_pt + i0 + mm] = sum;
+                    // four independent partial sums (fixed order): the LDS reads of a group are in flight together
+                    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                    int ff = 0;
+                    for (; ff + 4 <= nf; ff += 4) {
+                        s0 += src[ff];
+                        s1 += src[ff + 1];
+                        s2 += src[ff + 2];
+                        s3 += src[ff + 3];
+                    }
+                    for (; ff < nf; ++ff) s0 += src[ff];
+                    Vg[(int64_t)k * d.Ns + first_pt + i0 + mm] = (s0 + s1) + (s2 + s3);
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
         }
         if (on) {
             double* su = sU[js];
@@ -532,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
 #pragma unroll
             for (int k = 0; k < SRK_UG; ++k) atomicAdd(&su[k], acc[k]);
         }
+    }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < SRK_JF_SLOTS * SRK_UG; t += 256) {
@@ -542,7 +563,8 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
 
 void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, const double* cam, const int64_t* row_ptr,
                          const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
-                         const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin)
+                         const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
+                         int /* min_nf: shortest frame list of any task (not needed by this version) */)
 {
     if (n_tasks <= 0) return;
     hipLaunchKernelGGL(k_jac_runs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame,

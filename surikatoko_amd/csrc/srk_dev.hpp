@@ -44,12 +44,15 @@ void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, c
 void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
                           const int32_t* obs_frame, const int32_t* obs_pt, const double* obs_uv, double* W,
                           double* Vg, double* Ug, const int32_t* wg_jmin);
-// run-based single pass: one wave per task = up to SRK_JR_TASK_PTS_HOST consecutive landmarks with identical frame lists
-// (nf <= 64 frames); four consecutive tasks (one workgroup) must touch fewer than SRK_JF_SLOTS_HOST consecutive frames
-#define SRK_JR_TASK_PTS_HOST 36
+// run-based single pass: one wave per task = consecutive landmarks with identical frame lists (nf <= 64 frames), about
+// SRK_JR_TASK_PTS_MIN_HOST .. MAX_HOST of them; four consecutive tasks (one workgroup) must touch fewer than
+// SRK_JF_SLOTS_HOST consecutive frames
+#define SRK_JR_TASK_PTS_MIN_HOST 12
+#define SRK_JR_TASK_PTS_MAX_HOST 96 // = SRK_JR_XMAX of the kernel
 void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, const double* cam, const int64_t* row_ptr,
                          const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
-                         const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin);
+                         const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
+                         int min_nf /* shortest frame list of any task */);
 void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_obs, const double* pts,
                            const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
                            double* Ug);
