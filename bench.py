@@ -45,6 +45,7 @@ def parse():
                     help="one attempt slot (srk_ba_set_speculation off): kernels of different attempts never overlap, "
                          "so per-kernel durations under rocprofv3 are those of the kernel alone (profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-call", action="store_true", help="skip the one-call (upload + LM + download) latency probe")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
     ap.add_argument("--no-dense-probe", action="store_true")
     ap.add_argument("--rcs", choices=["chunks", "skyline", "dense"], default="chunks",
@@ -64,29 +65,155 @@ def algorithmic_bytes(N, M, O, ld, rcs_fill=1.0):
     return dict(jacobian=k2, error=k1, schur=k3, backsub=k5, solve_flops=k4_flops, solve_bytes=n * n * 8)
 
 
-def cpu_baseline(sample_name):
-    """The CPU oracle (plain-C restatement of the reference, block-sparse storage, Householder QR) timed on ONE host
-    core for ONE outer iteration of a bounded sample scene."""
+def _oracle_scene(orc, sc):
+    return orc.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, sc.row_ptr, sc.obs_frame, sc.obs_uv)
+
+
+def _gpu_rate(sa, name, steps, crit=None, f0=None):
+    """The GPU path on a CPU-baseline sample scene, same run: K iterations of one continuing optimise call."""
+    spec = sa.CONFIGS[name]
+    sc = sa.config_scene(name)
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        assert ba.upload(spec.f0 if f0 is None else f0, sc)
+        ba.optimize(crit, max_iterations=2)   # warm-up
+        ba.reset()
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ba.optimize(crit, max_iterations=steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r = ba.report
+        return {"iterations_per_s": r.iterations / dt if dt > 0 else None, "iterations": int(r.iterations),
+                "attempts": int(r.attempts), "seconds": dt}
+    finally:
+        ba.close()
+
+
+def cpu_baseline(sample_name, steps):
+    """The CPU oracle (plain-C restatement of the reference) timed on this box's host cores on bounded samples, next to
+    the GPU path on the SAME sample scenes in the same run.  BASELINE.md section 3 variants:
+      (ii)  block-sparse storage, Householder QR, ONE thread  -> the top-level "value" (1 outer iteration of the sample)
+      (iii) the same with OpenMP over points / rows / columns on the host's cores (bit-identical results)
+      (i)   the reference's literal dense storage and per-point n x n product (bundle-adj-kanatani.cpp:581,1891,1911),
+            one thread, on config 1 (n = 353); infeasible beyond config 2
+    and the derivative + Schur + back-substitution passes of the HEADLINE scene without its 9993^2 QR (hours)."""
     import surikatoko_amd as sa
     from oracle import oracle as orc
     spec = sa.CONFIGS[sample_name]
     sc = sa.config_scene(sample_name)
-    so = orc.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, sc.row_ptr, sc.obs_frame, sc.obs_uv)
-    t0 = time.perf_counter()
-    rc, rep = orc.compute_inplace(spec.f0, so, None, None, 1)
-    dt = time.perf_counter() - t0
+    host_cpus = os.cpu_count() or 1
+
+    def phases(rep):
+        return {"derivatives": rep.sec_derivatives, "schur": rep.sec_schur, "solve": rep.sec_solve,
+                "backsub": rep.sec_backsub, "apply": rep.sec_apply, "error": rep.sec_error}
+
+    def run(scene, f0, threads=1, max_it=1, dense=False, allowed=None):
+        orc.set_threads(threads)
+        try:
+            so = _oracle_scene(orc, scene)
+            t0 = time.perf_counter()
+            rc, rep = orc.compute_inplace(f0, so, allowed, None, max_it, dense_literal=dense)
+            dt = time.perf_counter() - t0
+        finally:
+            orc.set_threads(1)
+        return {"iterations_per_s": rep.iterations / dt if dt > 0 and rep.iterations else None,
+                "iterations": int(rep.iterations), "attempts": int(rep.attempts), "seconds": dt,
+                "phase_seconds": phases(rep), "cores": threads}
+
+    one = run(sc, spec.f0)                                                   # (ii)
+    threads = max(1, min(host_cpus, 64))
+    allc = run(sc, spec.f0, threads=threads)                                 # (iii)
+    c1 = sa.config_scene("C1_dino_standin")
+    dense = run(c1, 600.0, max_it=2, dense=True, allowed=4.56e-8)            # (i)
+    c1_sparse = run(c1, 600.0, max_it=2, allowed=4.56e-8)
+    head = None
+    try:                                                                     # headline scene without the QR
+        orc.set_skip_solve(True)
+        hs = sa.config_scene("C3_1kcam_100kpt")
+        head = run(hs, sa.CONFIGS["C3_1kcam_100kpt"].f0)
+        head["note"] = ("C3_1kcam_100kpt, one attempt of derivatives + Schur + back-substitution + error on one core; the "
+                        "Householder QR of its 9993^2 reduced system (4/3 n^3 = 1.3e12 flops) is skipped -- it is what "
+                        "makes the whole iteration infeasible on the CPU; see the C2 sample for a complete iteration")
+    except Exception as e:  # noqa: BLE001
+        head = {"failed": repr(e)}
+    finally:
+        orc.set_skip_solve(False)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(4.56e-8)
+    gpu_sample = _gpu_rate(sa, sample_name, steps)
+    gpu_c1 = _gpu_rate(sa, "C1_dino_standin", 10, crit=crit, f0=600.0)
     return {
-        "value": rep.iterations / dt if dt > 0 else None,
+        "value": one["iterations_per_s"],
         "unit": "iterations/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"1 outer LM iteration ({rep.attempts} attempt) of {sample_name}: {sc.M} cams / {sc.N} pts / "
-                  f"{sc.O} obs; block-sparse CPU oracle, Householder QR of the {10 * sc.M - 7}^2 reduced system",
-        "seconds": dt,
-        "phase_seconds": {"derivatives": rep.sec_derivatives, "schur": rep.sec_schur, "solve": rep.sec_solve,
-                          "backsub": rep.sec_backsub, "apply": rep.sec_apply, "error": rep.sec_error},
-        "host_cpus": os.cpu_count(),
+        "sample": f"1 outer LM iteration ({one['attempts']} attempt) of {sample_name}: {sc.M} cams / {sc.N} pts / "
+                  f"{sc.O} obs; block-sparse CPU oracle, Householder QR of the {10 * sc.M - 7}^2 reduced system "
+                  "(BASELINE.md variant ii); NOT the headline scene -- see 'gpu_on_sample' for the GPU path on this one",
+        "seconds": one["seconds"],
+        "phase_seconds": one["phase_seconds"],
+        "host_cpus": host_cpus,
+        "gpu_on_sample": gpu_sample,
+        "gpu_over_cpu_on_sample": (gpu_sample["iterations_per_s"] / one["iterations_per_s"]
+                                   if gpu_sample["iterations_per_s"] and one["iterations_per_s"] else None),
+        "variants": {
+            "ii_sparse_1core": dict(one, scene=sample_name),
+            "iii_sparse_allcore": dict(allc, scene=sample_name,
+                                       note="OpenMP: derivatives over points / frames, Schur sum by row ownership (every "
+                                            "entry keeps its sequential summation order), QR reflector application over "
+                                            "columns, back-substitution over points; results bit-identical to one core"),
+            "i_dense_literal_1core": dict(dense, scene="C1_dino_standin", sparse_1core_same_run=c1_sparse,
+                                          gpu_same_scene=gpu_c1,
+                                          note="reference storage: dense 3 x n row-block per point and an n x n product "
+                                               "per point (n = 353); 2 outer iterations with the dino flagfile's threshold"),
+            "headline_scene_without_qr_1core": head,
+        },
     }
+
+
+def one_call_latency(sa):
+    """Wall time of ONE srk_ba_compute_inplace call (validation, landmark sort, grouping, solver plan, allocation, upload,
+    LM loop, download, revert) at the sizes the reference's callers use; never part of `value`.
+    * config 1 (demo-dino stand-in, per-frame K, f0 = 600, the dino flagfile's threshold);
+    * the multi-view-factorization flagfile scene (60 frames / 81 x 41 = 3321 points, shared K, f0 = 1, threshold 1e-3:
+      cpp_impl/flagfile-demo-multi-view-factorization.txt:7-20, multi-view-factorization.cpp:379-394), which the driver
+      hands to BA again every frame -- first call on a fresh handle, then the same call repeated on the warm handle."""
+    import torch
+    out = {}
+
+    def timed(ba, f0, scene, crit, max_it=0):
+        sg = scene.copy()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = ba.ComputeInplace(f0, sg, crit, max_it)
+        dt = 1e3 * (time.perf_counter() - t0)
+        r = ba.report
+        return {"ms": dt, "ms_lm_loop": r.ms_total, "iterations": int(r.iterations), "attempts": int(r.attempts),
+                "result": bool(ok), "status": ba.OptimizationStatusString()}
+
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(4.56e-8)
+    c1 = sa.config_scene("C1_dino_standin")
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        out["C1_dino_standin_first_call"] = timed(ba, 600.0, c1, crit)
+        out["C1_dino_standin_warm_handle"] = timed(ba, 600.0, c1, crit)
+    finally:
+        ba.close()
+    spec = sa.SceneSpec(n_frames=60, grid_nx=81, grid_ny=41, vis_window=0, f0=1.0)
+    sc = sa.generate_scene(spec)
+    mvf = sa.Scene(sc.points, sc.cam_R, sc.cam_T, sc.K[0:1], 1, sc.row_ptr, sc.obs_frame, sc.obs_uv)
+    crit = sa.BundleAdjustmentKanataniTermCriteria()
+    crit.AllowedReprojErrRelativeChange(1e-3)
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        out["mvf_60x3321_first_call"] = timed(ba, 1.0, mvf, crit)
+        out["mvf_60x3321_warm_handle"] = timed(ba, 1.0, mvf, crit)
+    finally:
+        ba.close()
+    return out
 
 
 def main():
@@ -230,12 +357,18 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this configuration (profiles/, rocprofv3 --pmc in
         # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH x2 correction); None when no profile matches
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r1", f"pmc_{args.config}.json")
-        if world == 1 and os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))["kernels"]
-            except Exception:
-                pmc = {}
+        pmc_source = None
+        for rnd in ("r2", "r1"):
+            pmc_path = os.path.join(ROOT, "profiles", rnd, f"pmc_{args.config}.json")
+            if world == 1 and os.path.exists(pmc_path):
+                try:
+                    pmc = json.load(open(pmc_path))["kernels"]
+                    pmc_source = (f"profiles/{rnd}/pmc_{args.config}.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes of this command (gfx950 FETCH x2 correction), NOT measured in this run; a kernel "
+                                  "that changed since keeps no entry")
+                    break
+                except Exception:
+                    pmc = {}
 
         def traffic(*names):
             vals = [pmc[n]["hbm_bytes_per_launch"] for n in names if n in pmc]
@@ -243,8 +376,10 @@ def main():
 
         def hbm(bytes_, ms, *kernel_names):
             a = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tr = traffic(*kernel_names)
             return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                    "traffic": traffic(*kernel_names), "ms": ms, "algorithmic_bytes": bytes_}
+                    "traffic": tr, "traffic_source": pmc_source if tr is not None else None, "ms": ms,
+                    "algorithmic_bytes": bytes_}
 
         kernels = {
             "jacobian_phase": hbm(ab["jacobian"], per_it["ms_jacobian"], "k_jac_fused"),
@@ -294,14 +429,31 @@ def main():
             "ms": per_attempt["ms_schur"], "algorithmic_flops": schur_flops, "algorithmic_bytes": ab["schur"],
             "note": "fp64 MFMA (v_mfma_f64_16x16x4: a run's landmark sum as a (10 nf)^2 x (3 np) matrix product); the time "
                     "is the Schur phase = this kernel + ~20 us of zeroing / assembly"}
-        # dominant kernel = the single kernel (or, for the solve, kernel class) with the largest share of the step.  The
-        # panel chain of the solve is larger in total but is ~24 latency-bound launches with no throughput roof.
+        # The factorisation + substitution phase as a whole, priced twice: the flops its launches execute (MFMA trailing
+        # and rank-64 updates as counted by the library while it issues them + n_sky pivots' worth of panel work, ~2 n b^2
+        # for a band of half-width b -- the MFMA count is the dominant term and the one used) against the fp64 MFMA peak,
+        # and the skyline of the system (read and written once) against HBM.  Neither roof is near: the phase is a chain
+        # of dependent launches, which is exactly why it carries the largest share of the step.
+        skyline_bytes = 2.0 * rcs_fill * 0.5 * (10 * M) ** 2 * 8
+        ms_sol = per_attempt["ms_solve"]
+        tf_sol = mfma_flops / (ms_sol * 1e-3) / 1e12 if ms_sol > 0 else 0.0
+        kernels["solve_phase"] = {
+            "bound": "mfma", "achieved": tf_sol, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf_sol / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "ms": ms_sol, "algorithmic_flops": mfma_flops,
+            "hbm_view": {"algorithmic_bytes": skyline_bytes,
+                         "achieved_GBs": skyline_bytes / (ms_sol * 1e-3) / 1e9 if ms_sol > 0 else 0.0,
+                         "frac_of_hbm_peak": (skyline_bytes / (ms_sol * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_sol > 0 else 0.0},
+            "ms_mfma_updates": ms_syrk, "ms_panel_chain": ms_sol - ms_syrk,
+            "note": "whole solve phase of one attempt (all levels of the nested dissection: gather, panels, updates, "
+                    "separator reduction, backward substitution, scatter); executed MFMA flops / phase time"}
+        # dominant = the largest share of the step among the kernels / kernel classes (the solve phase is one candidate)
         shares = {"jacobian_kernel": per_it["ms_jacobian_kernel"], "schur_kernel_fp64": per_it["ms_schur"],
-                  "solve_syrk_mfma": per_it["ms_solve_syrk"], "backsub_phase": per_it["ms_backsub"],
+                  "solve_phase": per_it["ms_solve"], "backsub_phase": per_it["ms_backsub"],
                   "error_phase": per_it["ms_error"]}
         dominant = max(shares, key=shares.get)
         roofline = dict(kernels[dominant])
         roofline["kernel"] = dominant
+        roofline["share_of_step_ms"] = shares
         out = {
             "metric": "BA iterations/sec",
             "value": iterations / dt if dt > 0 else 0.0,
@@ -328,6 +480,8 @@ def main():
                                       "judged in the reference's order (srk_ba_set_speculation)"},
             "iterations_done": iterations,
             "attempts_per_iteration": attempts_timed / max(iterations, 1),
+            "attempts_per_s": attempts_timed / dt if dt > 0 else 0.0,
+            "ms_per_attempt": 1e3 * dt / max(attempts_timed, 1),
             "first_iteration": first_iteration,
             "profiled_steps": prof_steps,
             "ms_per_iter": {"jacobian": per_it["ms_jacobian"], "schur": per_it["ms_schur"],
@@ -338,9 +492,14 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if world == 1 and not args.no_one_call:
+            try:
+                out["one_call_ms"] = one_call_latency(sa)
+            except Exception as e:  # noqa: BLE001
+                out["one_call_ms"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.steps)
             except Exception as e:  # the checker must never take the bench down
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -13,6 +13,9 @@
 #define _POSIX_C_SOURCE 199309L
 #include "ba_oracle.h"
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -20,6 +23,19 @@
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+
+/* Baseline variant (iii) of BASELINE.md: the same arithmetic with OpenMP over points / frames / columns.  Off by
+ * default (orc_threads == 1: every pragma below is disabled by its if() clause and the loops run in the reference's
+ * sequential order, which is what the parity tests pin); bench.py's cpu_baseline leg turns it on for a timing run.
+ * The threaded Schur sum and QR update keep every entry's summation order (see there), so results do not change. */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
+/* Timing hook of bench.py's cpu_baseline leg ONLY: skip the Householder QR of the reduced system (4/3 n^3 flops: hours
+ * at n = 9993) and continue with zero camera corrections, so that the derivative, Schur and back-substitution passes of
+ * the 1000-camera scene can be timed on the CPU.  Never set by a test; results are meaningless while it is on. */
+static int orc_skip_solve = 0;
+void orc_set_skip_solve(int on) { orc_skip_solve = on != 0; }
+int orc_get_threads(void) { return orc_threads; }
 
 static double now_sec(void)
 {
@@ -280,6 +296,7 @@ int orc_householder_qr_solve(int64_t n, double* A, const double* b, double* x)
             /* rows()==1: *this *= (1 - tau) -- no trailing columns when k == n-1 */
             c[k] *= (1 - t);
         } else if (t != 0) {
+#pragma omp parallel for schedule(static) num_threads(orc_threads) if (orc_threads > 1 && (n - k) * m > 400000)
             for (int64_t j = k + 1; j < n; ++j) {
                 double* cj = A + j * n + k;
                 double tmp = 0;
@@ -716,6 +733,7 @@ void orc_derivatives(double f0, int64_t N, const double* points, int32_t M, cons
     memset(Wpf, 0, sizeof(double) * (size_t)(30 * O));
 
     /* points loop BA:1163-1221 */
+#pragma omp parallel for schedule(static) num_threads(orc_threads) if (orc_threads > 1)
     for (int64_t i = 0; i < N; ++i) {
         const double* X = points + 3 * i;
         double* gp = gradE + 3 * i;
@@ -739,6 +757,7 @@ void orc_derivatives(double f0, int64_t N, const double* points, int32_t M, cons
     /* frames loop BA:1270-1359 */
     csc_t c;
     csc_build(N, M, row_ptr, obs_frame, &c);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads) if (orc_threads > 1)
     for (int32_t j = 0; j < M; ++j) {
         const double* R = cam_R + 9 * j;
         const double* T = cam_T + 3 * j;
@@ -819,7 +838,17 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
         Fd = (double*)malloc(sizeof(double) * (size_t)(3 * n));
         tmpd = (double*)malloc(sizeof(double) * (size_t)(3 * n));
     }
-    /* per point BA:1862-1898 */
+    /* per point BA:1862-1898.  threads > 1 (sparse path only): every thread walks ALL points in the reference's order
+     * but applies only the updates of the rows of S (and entries of rhs) it owns (row index modulo the thread count), so
+     * every entry still receives its terms in the sequential order: the threaded result is bit-identical. */
+    const int nth = (orc_threads > 1 && !dense_literal) ? orc_threads : 1;
+#pragma omp parallel num_threads(nth) if (nth > 1)
+    {
+#ifdef _OPENMP
+    const int tid = nth > 1 ? omp_get_thread_num() : 0;
+#else
+    const int tid = 0;
+#endif
     for (int64_t i = 0; i < N; ++i) {
         double E[9], Einv[9], det;
         memcpy(E, Vpp + 9 * i, sizeof E);
@@ -859,7 +888,7 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
                                      Wa[20 + fa] * Einv[2 * 3 + k];
                 for (int fa = 0; fa < 10; ++fa) {
                     int64_t ra = red[10 * (int64_t)obs_frame[oa] + fa];
-                    if (ra < 0) continue;
+                    if (ra < 0 || (nth > 1 && ra % nth != tid)) continue;
                     for (int64_t ob = o0; ob < o1; ++ob) {
                         const double* Wb = Wpf + 30 * ob;
                         for (int fb = 0; fb < 10; ++fb) {
@@ -873,6 +902,7 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
             }
         }
     }
+    } /* parallel region */
     /* rhs -= normalized frame derivatives BA:1902-1908 */
     for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi)
         if (red[fi] >= 0) rhs[red[fi]] -= gradE[3 * N + fi];
@@ -883,12 +913,16 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
     double t1 = now_sec();
     /* BA:1911 householderQr().solve */
     double* dc = (double*)malloc(sizeof(double) * (size_t)n);
-    int ok = orc_householder_qr_solve(n, S, rhs, dc);
+    int ok = 1;
+    if (orc_skip_solve) memset(dc, 0, sizeof(double) * (size_t)n);
+    else ok = orc_householder_qr_solve(n, S, rhs, dc);
     double t2 = now_sec();
     if (ok) {
         /* back substitution BA:1919-1960 and gap fill BA:1600-1679 */
         memset(corrections, 0, sizeof(double) * (size_t)(3 * N + 10 * (int64_t)M));
-        for (int64_t i = 0; i < N && ok; ++i) {
+        int all_finite = 1;
+#pragma omp parallel for schedule(static) num_threads(orc_threads) reduction(&& : all_finite) if (orc_threads > 1)
+        for (int64_t i = 0; i < N; ++i) {
             double E[9], Einv[9], det;
             memcpy(E, Vpp + 9 * i, sizeof E);
             E[0] *= 1 + c; E[4] *= 1 + c; E[8] *= 1 + c;
@@ -905,9 +939,10 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
             double b[3] = { acc[0] + g[0], acc[1] + g[1], acc[2] + g[2] };
             for (int pv = 0; pv < 3; ++pv) {
                 dx[pv] = -Einv[3 * pv] * b[0] - Einv[3 * pv + 1] * b[1] - Einv[3 * pv + 2] * b[2];
-                if (!isfinite(dx[pv])) ok = 0; /* :1953-1954 */
+                if (!isfinite(dx[pv])) all_finite = 0; /* :1953-1954 (the reference stops at the first; the result is discarded either way) */
             }
         }
+        ok = all_finite;
         for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi) corrections[3 * N + fi] = red[fi] >= 0 ? dc[red[fi]] : 0.0;
     }
     double t3 = now_sec();

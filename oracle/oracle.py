@@ -204,6 +204,21 @@ def compute_inplace(f0, sc, allowed_err_change=None, max_hessian_factor=None, ma
     return rc, rep
 
 
+def set_threads(n):
+    """Baseline variant (iii) only: OpenMP threads of the derivative / Schur / QR-update / back-substitution loops
+    (1 = the reference's sequential order, what every parity test uses)."""
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
+def set_skip_solve(on):
+    """bench.py's cpu_baseline leg only: time derivatives + Schur + back-substitution without the dense QR."""
+    lib().orc_set_skip_solve(C.c_int(int(bool(on))))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
+
+
 def status_string(status):
     return lib().orc_status_string(C.c_int(status)).decode()
 
