@@ -179,7 +179,8 @@ def one_call_latency(sa):
     * config 1 (demo-dino stand-in, per-frame K, f0 = 600, the dino flagfile's threshold);
     * the multi-view-factorization flagfile scene (60 frames / 81 x 41 = 3321 points, shared K, f0 = 1, threshold 1e-3:
       cpp_impl/flagfile-demo-multi-view-factorization.txt:7-20, multi-view-factorization.cpp:379-394), which the driver
-      hands to BA again every frame -- first call on a fresh handle, then the same call repeated on the warm handle."""
+      hands to BA again every frame -- first call on a fresh handle, then the same call repeated on the warm handle;
+      five LM iterations each."""
     import torch
     out = {}
 
@@ -209,8 +210,10 @@ def one_call_latency(sa):
     crit.AllowedReprojErrRelativeChange(1e-3)
     ba = sa.BundleAdjustmentKanatani(0)
     try:
-        out["mvf_60x3321_first_call"] = timed(ba, 1.0, mvf, crit)
-        out["mvf_60x3321_warm_handle"] = timed(ba, 1.0, mvf, crit)
+        # (the reference has no iteration cap and this all-visible scene creeps for thousands of iterations under the 1e-3
+        # threshold; the probe is about the fixed cost of a call, so it stops after five)
+        out["mvf_60x3321_first_call"] = timed(ba, 1.0, mvf, crit, 5)
+        out["mvf_60x3321_warm_handle"] = timed(ba, 1.0, mvf, crit, 5)
     finally:
         ba.close()
     return out

@@ -838,17 +838,53 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
         Fd = (double*)malloc(sizeof(double) * (size_t)(3 * n));
         tmpd = (double*)malloc(sizeof(double) * (size_t)(3 * n));
     }
-    /* per point BA:1862-1898.  threads > 1 (sparse path only): every thread walks ALL points in the reference's order
-     * but applies only the updates of the rows of S (and entries of rhs) it owns (row index modulo the thread count), so
-     * every entry still receives its terms in the sequential order: the threaded result is bit-identical. */
-    const int nth = (orc_threads > 1 && !dense_literal) ? orc_threads : 1;
-#pragma omp parallel num_threads(nth) if (nth > 1)
-    {
-#ifdef _OPENMP
-    const int tid = nth > 1 ? omp_get_thread_num() : 0;
-#else
-    const int tid = 0;
-#endif
+    /* per point BA:1862-1898.  threads > 1 (sparse path only, baseline variant iii): the same terms, walked frame-major
+     * so that no two threads touch the same row of S: a thread takes whole frames j, and for every observation (i, j) of
+     * frame j -- in ascending landmark order, as the sequential loop meets them -- applies landmark i's updates of the ten
+     * rows of frame j.  Every entry of S and rhs receives its terms in the sequential order: bit-identical results. */
+    if (orc_threads > 1 && !dense_literal) {
+        double* Einv_all = (double*)malloc(sizeof(double) * (size_t)(9 * (N > 0 ? N : 1)));
+        char* ok_all = (char*)malloc((size_t)(N > 0 ? N : 1));
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
+        for (int64_t i = 0; i < N; ++i) {
+            double E[9], det;
+            memcpy(E, Vpp + 9 * i, sizeof E);
+            E[0] *= 1 + c; E[4] *= 1 + c; E[8] *= 1 + c;
+            ok_all[i] = (char)orc_inverse3x3_with_check(E, Einv_all + 9 * i, &det);
+        }
+        csc_t cs;
+        csc_build(N, M, row_ptr, obs_frame, &cs);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads)
+        for (int32_t j = 0; j < M; ++j) {
+            for (int64_t k = cs.col_ptr[j]; k < cs.col_ptr[j + 1]; ++k) {
+                const int64_t oa = cs.obs[k], i = cs.pnt[k];
+                if (!ok_all[i]) continue;
+                const double* Einv = Einv_all + 9 * i;
+                const double* g = gradE + 3 * i;
+                const double* Wa = Wpf + 30 * oa;
+                double tmp[10][3];
+                for (int fa = 0; fa < 10; ++fa)
+                    for (int kk = 0; kk < 3; ++kk)
+                        tmp[fa][kk] = Wa[fa] * Einv[0 * 3 + kk] + Wa[10 + fa] * Einv[1 * 3 + kk] + Wa[20 + fa] * Einv[2 * 3 + kk];
+                for (int fa = 0; fa < 10; ++fa) {
+                    int64_t ra = red[10 * (int64_t)j + fa];
+                    if (ra < 0) continue;
+                    for (int64_t ob = row_ptr[i]; ob < row_ptr[i + 1]; ++ob) {
+                        const double* Wb = Wpf + 30 * ob;
+                        for (int fb = 0; fb < 10; ++fb) {
+                            int64_t rb = red[10 * (int64_t)obs_frame[ob] + fb];
+                            if (rb < 0) continue;
+                            S[rb * n + ra] -= tmp[fa][0] * Wb[fb] + tmp[fa][1] * Wb[10 + fb] + tmp[fa][2] * Wb[20 + fb];
+                        }
+                    }
+                    rhs[ra] += tmp[fa][0] * g[0] + tmp[fa][1] * g[1] + tmp[fa][2] * g[2];
+                }
+            }
+        }
+        csc_free(&cs);
+        free(Einv_all);
+        free(ok_all);
+    } else
     for (int64_t i = 0; i < N; ++i) {
         double E[9], Einv[9], det;
         memcpy(E, Vpp + 9 * i, sizeof E);
@@ -888,7 +924,7 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
                                      Wa[20 + fa] * Einv[2 * 3 + k];
                 for (int fa = 0; fa < 10; ++fa) {
                     int64_t ra = red[10 * (int64_t)obs_frame[oa] + fa];
-                    if (ra < 0 || (nth > 1 && ra % nth != tid)) continue;
+                    if (ra < 0) continue;
                     for (int64_t ob = o0; ob < o1; ++ob) {
                         const double* Wb = Wpf + 30 * ob;
                         for (int fb = 0; fb < 10; ++fb) {
@@ -902,7 +938,6 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
             }
         }
     }
-    } /* parallel region */
     /* rhs -= normalized frame derivatives BA:1902-1908 */
     for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi)
         if (red[fi] >= 0) rhs[red[fi]] -= gradE[3 * N + fi];
