@@ -185,12 +185,108 @@ struct CholItem {
 };
 struct CholBatch { CholItem it[SRK_MAX_CHUNKS]; };
 struct CholStep { int64_t v[SRK_MAX_CHUNKS]; }; // one per-launch value per item; < 0 = item takes no part
-struct CholHostItem { const int64_t* row_end; const int64_t* col_begin; }; // host skylines of an item (may be NULL)
+// host side of an item: its skylines (may be NULL) and which of its border rows are structurally zero when.  The border
+// rows [r2_begin, r2_end) of a chunk are [separator above | separator below], r2_split between them.  A chunk without a
+// separator above (the first one) never needs the first part; the rows of the separator below stay zero until the
+// elimination reaches column bot_first_col (they couple with the chunk's last bandwidth of columns only), and for good
+// in the last chunk.  Sweeping and updating all-zero rows is exact but wasted: at the first step of a 512-column chunk
+// a third of the rows and more than half of the trailing update.
+struct CholHostItem {
+    const int64_t* row_end;
+    const int64_t* col_begin;
+    int64_t r2_split = 0, bot_first_col = 0;
+    bool has_top = true, has_bot = true;
+};
+
+// ---------------------------------------------------------------- inverse of a factored 64x64 diagonal tile
+// Z = L^-1 (lower triangular) by blocked inversion: the four 16x16 diagonal blocks by register-resident forward
+// substitution (16 dependent steps), then two levels of
+//     [ L11  0  ]^-1   [ Z11            0  ]
+//     [ L21 L22 ]    = [ -Z22 L21 Z11  Z22 ]
+// as small LDS matrix products over all 256 threads.  It turns the 64 dependent steps of each backward tile solve into
+// one matrix-vector product (k_bwd256).  sL: the factor (zeros above the diagonal), row stride NB + 2; out: row-major
+// 64 x 64 in global memory.  Runs in the extra workgroup of k_panel, beside the row sweeps of the other workgroups.
+__device__ __forceinline__ void tile_inverse(const double (*sL)[NB + 2], double (*sZ)[NB + 1], double (*sT)[33],
+                                             double* sR, double* __restrict__ out)
+{
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256) sZ[e >> 6][e & 63] = 0.0;
+    // reciprocals of the diagonal once, in parallel: an IEEE divide inside each of the 16 dependent substitution steps
+    // below would cost more than the rest
+    if (t < NB) sR[t] = 1.0 / sL[t][t];
+    __syncthreads();
+    if (t < 64) { // thread (b, c): column c of the inverse of diagonal block b, right-looking in registers
+        const int o = 16 * (t >> 4), c = t & 15;
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double z = (i >= c) ? acc[i] * sR[o + i] : 0.0;
+            sZ[o + i][o + c] = z;
+#pragma unroll
+            for (int k = i + 1; k < 16; ++k) acc[k] = fma(-sL[o + k][o + i], z, acc[k]);
+        }
+    }
+    __syncthreads();
+    // level 32: pairs (block 1 | block 0) and (block 3 | block 2); thread -> outputs idx = t, t + 256
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int idx = t + 256 * h, pr = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        const int o1 = 32 * pr, o2 = o1 + 16;
+        double sum = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sum = fma(sL[o2 + i][o1 + m], sZ[o1 + m][o1 + j], sum);
+        sT[16 * pr + i][j] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int idx = t + 256 * h, pr = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        const int o1 = 32 * pr, o2 = o1 + 16;
+        double sum = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sum = fma(sZ[o2 + i][o2 + m], sT[16 * pr + m][j], sum);
+        sZ[o2 + i][o1 + j] = -sum;
+    }
+    __syncthreads();
+    // level 64: T = L21 Z11 (32x32), X = -Z22 T; thread -> outputs (i, j), (i + 8, j), (i + 16, j), (i + 24, j)
+    {
+        const int i0 = t >> 5, j = t & 31;
+        double sum[4] = { 0, 0, 0, 0 };
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            const double zv = sZ[m][j];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sum[h] = fma(sL[32 + i0 + 8 * h][m], zv, sum[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sT[i0 + 8 * h][j] = sum[h];
+    }
+    __syncthreads();
+    {
+        const int i0 = t >> 5, j = t & 31;
+        double sum[4] = { 0, 0, 0, 0 };
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            const double tv = sT[m][j];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sum[h] = fma(sZ[32 + i0 + 8 * h][32 + m], tv, sum[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sZ[32 + i0 + 8 * h][j] = -sum[h];
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 256) out[e] = sZ[e >> 6][e & 63];
+}
 
 // ---------------------------------------------------------------- inner panel: potrf + trsm + forward substitution
 // d = index of the 64-wide diagonal tile.  Rows (d+1)*64 .. row_end-1 of columns [64 d, 64 d + 64) become L.
 // w is the running right-hand side: y_d = L_dd^-1 w_d is published to y, and w_r -= L[r, d-cols] . y_d for the
 // rows below (so the forward substitution L y = b costs no extra launches).
+// Workgroup 0 of every item is the INVERSE workgroup: it factors the tile like the others, then forms L_dd^-1 for the
+// backward substitution (k_bwd256) while the other workgroups sweep their rows -- about as long as a sweep, so the
+// five k_dinv launches a solve used to need (12 us each) cost nothing.  Workgroups 1.. take PANEL_ROWS rows each.
 #ifdef SRK_PANEL_STAMPS
 __device__ long long g_panel_stamps[16];
 #define STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d == 40) g_panel_stamps[k] = wall_clock64(); } while (0)
@@ -198,22 +294,28 @@ __device__ long long g_panel_stamps[16];
 #define STAMP(k)
 #endif
 #define PANEL_ROWS 63 // matrix rows per workgroup; the 64th quad carries the right-hand side as one more row
-__global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep rend, int64_t d, int* __restrict__ info)
+__global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                int64_t d, int* __restrict__ info)
 {
     const int64_t row_end = rend.v[blockIdx.z];
     if (row_end < 0) return;
     double* __restrict__ A = B.it[blockIdx.z].A;
     double* __restrict__ w = B.it[blockIdx.z].w;
     double* __restrict__ y = B.it[blockIdx.z].y;
-    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin, r2_end = B.it[blockIdx.z].r2_end;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = r2b.v[blockIdx.z], r2_end = r2e.v[blockIdx.z]; // live border rows of this step
+    const bool inv_wg = blockIdx.x == 0;
+    const int64_t rblk = (int64_t)blockIdx.x - 1; // row block of a sweeping workgroup
+    int64_t blocks;
     {
         int64_t rows = row_end - (d + 1) * NB;
         if (rows < 0) rows = 0;
         rows += r2_end - r2_begin;
-        const int64_t blocks = rows > 0 ? (rows + PANEL_ROWS - 1) / PANEL_ROWS : 1;
-        if ((int64_t)blockIdx.x >= blocks) return; // the grid is sized for the largest item of the batch
+        blocks = (rows + PANEL_ROWS - 1) / PANEL_ROWS;
+        if (!inv_wg && rblk >= blocks) return; // the grid is sized for the largest item of the batch
     }
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
+    __shared__ double sZ[NB][NB + 1]; // inverse workgroup only
+    __shared__ double sT[32][33];
     __shared__ __attribute__((aligned(16))) double sCol[8 * NB]; // potrf64: panel [64][4] + finals [64][4]
     __shared__ double sDiag[NB];
     __shared__ double sInv[NB];
@@ -240,19 +342,14 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     STAMP(1);
     bool bad = potrf64(sD, sCol, sDiag, sInv);
     STAMP(2);
-    if (bad && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(info, 1);
-    if (blockIdx.x == 0) {
-        // L_dd goes to this tile's slot of the Dinv buffer (k_dinv inverts it there), NOT back into A: the other
-        // workgroups of this launch read the unfactored tile from A when they start, and nothing orders their start
-        // before this store -- a grid larger than the chip, or a GPU shared with other processes, starts some of them
-        // after workgroup 0 is done.  No later kernel reads a diagonal tile of A.
-        const int i = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
-        double2* dst = reinterpret_cast<double2*>(B.it[blockIdx.z].dinv + d * NB * NB + (int64_t)i * NB + cb);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            int c = cb + 2 * t;
-            dst[t] = make_double2(sD[i][c], sD[i][c + 1]); // zeros above the diagonal
-        }
+    if (bad && inv_wg && threadIdx.x == 0) atomicOr(info, 1);
+    // The factored tile is never stored back into A: the other workgroups of this launch read the unfactored tile from
+    // A when they start, and nothing orders their start before such a store -- a grid larger than the chip, or a GPU
+    // shared with other processes, starts some of them late.  No later kernel reads a diagonal tile of A or L_dd itself:
+    // the backward substitution works with the inverse, which goes to this tile's slot of the Dinv buffer.
+    if (inv_wg && blocks > 0) {
+        tile_inverse(sD, sZ, sT, sDiag, B.it[blockIdx.z].dinv + d * NB * NB);
+        return;
     }
     STAMP(3);
     // Row sweep X = A[rows, panel] L_dd^-T, four columns at a time.  A row is split over the 4 lanes of a quad (lane q
@@ -264,9 +361,11 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     // (the separator rows of a chunked factorisation; empty otherwise)
     int64_t rows1 = row_end - (k0 + NB);
     if (rows1 < 0) rows1 = 0;
-    const int64_t ridx = (int64_t)blockIdx.x * PANEL_ROWS + qd;
+    // (an item without rows below this tile has no sweeping workgroup: the inverse workgroup then runs the sweep for the
+    // right-hand side quad alone, with every matrix row dead, before it inverts the tile)
+    const int64_t ridx = (inv_wg ? 0 : rblk) * PANEL_ROWS + qd;
     const int64_t r = ridx < rows1 ? k0 + NB + ridx : r2_begin + (ridx - rows1);
-    const bool live = !is_rhs && ridx < rows1 + (r2_end - r2_begin);
+    const bool live = !is_rhs && !inv_wg && ridx < rows1 + (r2_end - r2_begin);
     double* row = is_rhs ? (w + k0) : (A + (live ? r : k0) * ld + k0); // dead rows read the diagonal tile (harmless)
     double a[16];
 #pragma unroll
@@ -312,13 +411,16 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
         for (int m = 0; m < 16; ++m) sy[4 * m + q] = a[m];
     }
     __syncthreads();
-    if (is_rhs) {
-        if (blockIdx.x == 0) {
+    if (is_rhs && (inv_wg || rblk == 0)) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m) y[k0 + 4 * m + q] = a[m];
-        }
+        for (int m = 0; m < 16; ++m) y[k0 + 4 * m + q] = a[m];
+    }
+    if (inv_wg) { // only reached when the item has no rows below the tile
+        __syncthreads();
+        tile_inverse(sD, sZ, sT, sDiag, B.it[blockIdx.z].dinv + d * NB * NB);
         return;
     }
+    if (is_rhs) return;
     // w_r -= L[r, panel] . y_d  (the forward substitution's update of the rows below)
     double dot = 0;
 #pragma unroll
@@ -339,16 +441,17 @@ extern "C" void srk_dbg_panel_stamps(long long* out) { hipMemcpyFromSymbol(out, 
 // ---------------------------------------------------------------- 64-deep update inside the outer panel (MFMA)
 // A[rt, ct] -= L[rt, d] L[ct, d]^T for row tiles rt > d (rows < row_end) and column tiles d < ct <= c_hi, ct <= rt.
 // grid = (row tiles, column tiles).  4 waves, each a 32x32 quadrant = 2x2 accumulator tiles, K = 64.
-__global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep rend, int64_t d, int64_t c_hi)
+__global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                int64_t d, int64_t c_hi)
 {
     __shared__ double sA[NB][LDSP];
     __shared__ double sB[NB][LDSP];
     if (rend.v[blockIdx.z] < 0) return;
     double* __restrict__ A = B.it[blockIdx.z].A;
-    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = r2b.v[blockIdx.z];
     int64_t tiles1 = (rend.v[blockIdx.z] - (d + 1) * NB) / NB;
     if (tiles1 < 0) tiles1 = 0;
-    if ((int64_t)blockIdx.x >= tiles1 + (B.it[blockIdx.z].r2_end - r2_begin) / NB) return;
+    if ((int64_t)blockIdx.x >= tiles1 + (r2e.v[blockIdx.z] - r2_begin) / NB) return;
     // row tiles: `tiles1` tiles right below the diagonal tile, then the border tiles starting at r2_begin
     const bool in1 = (int64_t)blockIdx.x < tiles1;
     int64_t rt = d + 1 + blockIdx.x;
@@ -411,18 +514,19 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
 // C[ti, tj] -= P[ti] P[tj]^T over the 128x128 tile pairs ti >= tj of rows/cols [c_first, row_end), P = the 256
 // panel columns starting at k0.  One workgroup per tile pair (linear index -> triangular pair).
-__global__ __launch_bounds__(256, 2) void k_trail(const CholBatch B, const CholStep rend, int64_t k0, int64_t c_first)
+__global__ __launch_bounds__(256, 2) void k_trail(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                   int64_t k0, int64_t c_first)
 {
     __shared__ double sA[2][TL][KCP];
     __shared__ double sB[2][TL][KCP];
     if (rend.v[blockIdx.z] < 0) return;
     double* __restrict__ A = B.it[blockIdx.z].A;
-    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = r2b.v[blockIdx.z];
     int64_t T1 = (rend.v[blockIdx.z] - c_first) / TL;
     if (T1 < 0) T1 = 0;
     int64_t p = blockIdx.x;
     {
-        const int64_t T = T1 + (B.it[blockIdx.z].r2_end - r2_begin) / TL;
+        const int64_t T = T1 + (r2e.v[blockIdx.z] - r2_begin) / TL;
         if (p >= T * (T + 1) / 2) return;
     }
     int ti = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
@@ -515,18 +619,19 @@ __global__ __launch_bounds__(256, 2) void k_trail(const CholBatch B, const CholS
 // ---------------------------------------------------------------- trailing update, small-skyline variant
 // Same contraction as k_trail on 64x64 tiles (4x the workgroups, a quarter of the serial work each): when only a few
 // 128-tiles are inside the skyline the update is latency-bound and the grid, not the tile shape, sets its time.
-__global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholStep rend, int64_t k0, int64_t c_first)
+__global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                  int64_t k0, int64_t c_first)
 {
     __shared__ double sA[NB][LDSP];
     __shared__ double sB[NB][LDSP];
     if (rend.v[blockIdx.z] < 0) return;
     double* __restrict__ A = B.it[blockIdx.z].A;
-    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = B.it[blockIdx.z].r2_begin;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = r2b.v[blockIdx.z];
     int64_t T1 = (rend.v[blockIdx.z] - c_first) / NB;
     if (T1 < 0) T1 = 0;
     int64_t p = blockIdx.x;
     {
-        const int64_t T = T1 + (B.it[blockIdx.z].r2_end - r2_begin) / NB;
+        const int64_t T = T1 + (r2e.v[blockIdx.z] - r2_begin) / NB;
         if (p >= T * (T + 1) / 2) return;
     }
     int ti = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
@@ -601,101 +706,7 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
 }
 
 // ---------------------------------------------------------------- backward substitution L^T x = y
-// k_dinv: Dinv[d] = L_dd^-1 (lower triangular, 64x64) for every diagonal tile at once -- it turns the 64 dependent
-// steps of each triangular solve into one small matrix-vector product.  Blocked inversion: the four 16x16 diagonal
-// blocks by register-resident forward substitution (16 dependent steps), then two levels of
-//     [ L11  0  ]^-1   [ Z11            0  ]
-//     [ L21 L22 ]    = [ -Z22 L21 Z11  Z22 ]
-// as small LDS matrix products over all 256 threads (a 64-step substitution per column took ~100 us per launch).
-__global__ __launch_bounds__(256) void k_dinv(const CholBatch B)
-{
-    __shared__ double sL[NB][NB + 1];
-    __shared__ double sZ[NB][NB + 1];
-    __shared__ double sT[32][33];
-    const int64_t k0 = (int64_t)blockIdx.x * NB;
-    if (k0 >= B.it[blockIdx.z].ncols) return;
-    double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
-    const int t = threadIdx.x;
-    {
-        const double* Ld = Dinv + (int64_t)blockIdx.x * NB * NB; // k_panel left L_dd in this tile's slot
-        for (int e = t; e < NB * NB; e += 256) {
-            int i = e >> 6, c = e & 63;
-            sL[i][c] = (c <= i) ? Ld[e] : 0.0;
-            sZ[i][c] = 0.0;
-        }
-    }
-    __syncthreads();
-    // reciprocals of the diagonal once, in parallel: an IEEE divide inside each of the 16 dependent substitution steps
-    // below would cost more than the rest of the kernel
-    __shared__ double sR[NB];
-    if (t < NB) sR[t] = 1.0 / sL[t][t];
-    __syncthreads();
-    if (t < 64) { // thread (b, c): column c of the inverse of diagonal block b, right-looking in registers
-        const int o = 16 * (t >> 4), c = t & 15;
-        double acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double z = (i >= c) ? acc[i] * sR[o + i] : 0.0;
-            sZ[o + i][o + c] = z;
-#pragma unroll
-            for (int k = i + 1; k < 16; ++k) acc[k] = fma(-sL[o + k][o + i], z, acc[k]);
-        }
-    }
-    __syncthreads();
-    // level 32: pairs (block 1 | block 0) and (block 3 | block 2); thread -> outputs idx = t, t + 256
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int idx = t + 256 * h, pr = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
-        const int o1 = 32 * pr, o2 = o1 + 16;
-        double sum = 0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) sum = fma(sL[o2 + i][o1 + m], sZ[o1 + m][o1 + j], sum);
-        sT[16 * pr + i][j] = sum;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int idx = t + 256 * h, pr = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
-        const int o1 = 32 * pr, o2 = o1 + 16;
-        double sum = 0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) sum = fma(sZ[o2 + i][o2 + m], sT[16 * pr + m][j], sum);
-        sZ[o2 + i][o1 + j] = -sum;
-    }
-    __syncthreads();
-    // level 64: T = L21 Z11 (32x32), X = -Z22 T; thread -> outputs (i, j), (i + 8, j), (i + 16, j), (i + 24, j)
-    {
-        const int i0 = t >> 5, j = t & 31;
-        double sum[4] = { 0, 0, 0, 0 };
-#pragma unroll 8
-        for (int m = 0; m < 32; ++m) {
-            const double zv = sZ[m][j];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) sum[h] = fma(sL[32 + i0 + 8 * h][m], zv, sum[h]);
-        }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) sT[i0 + 8 * h][j] = sum[h];
-    }
-    __syncthreads();
-    {
-        const int i0 = t >> 5, j = t & 31;
-        double sum[4] = { 0, 0, 0, 0 };
-#pragma unroll 8
-        for (int m = 0; m < 32; ++m) {
-            const double tv = sT[m][j];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) sum[h] = fma(sZ[32 + i0 + 8 * h][32 + m], tv, sum[h]);
-        }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) sZ[32 + i0 + 8 * h][j] = -sum[h];
-    }
-    __syncthreads();
-    double* out = Dinv + (int64_t)blockIdx.x * NB * NB;
-    for (int e = t; e < NB * NB; e += 256) out[e] = sZ[e >> 6][e & 63];
-}
-
+// (the inverses of the diagonal tiles come from the inverse workgroup of k_panel)
 // step K (descending, 256 rows): x_K = L_KK^-T y_K by four tile back-substitutions with the explicit tile inverses
 // (every workgroup, redundantly), then y_j -= sum_i L[256 K + i, j] x_K[i] for this workgroup's 64 columns
 // j in [col_begin, 256 K).  Every product is "one column per lane, the rows split over the four waves, partial sums
@@ -790,8 +801,8 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
     for (int64_t K = 0; K < nout; ++K) {
         const int64_t k0 = K * NBO;
-        CholStep st;
-        for (int i = 0; i < SRK_MAX_CHUNKS; ++i) st.v[i] = -1;
+        CholStep st, r2b, r2e;
+        for (int i = 0; i < SRK_MAX_CHUNKS; ++i) st.v[i] = -1, r2b.v[i] = r2e.v[i] = 0;
         for (int i = 0; i < n; ++i) {
             const int64_t ncols = B.it[i].ncols;
             if (K >= ncols / NBO) continue;
@@ -799,24 +810,32 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
             if (rend < k0 + NBO) rend = k0 + NBO;
             if (rend > ncols) rend = ncols;
             st.v[i] = rend;
+            // live border rows of this step
+            r2b.v[i] = B.it[i].r2_begin;
+            r2e.v[i] = B.it[i].r2_end;
+            if (B.it[i].r2_end > B.it[i].r2_begin) {
+                if (!H[i].has_top) r2b.v[i] = H[i].r2_split;
+                if (!H[i].has_bot || k0 + NBO <= H[i].bot_first_col) r2e.v[i] = H[i].r2_split;
+                if (r2e.v[i] < r2b.v[i]) r2e.v[i] = r2b.v[i];
+            }
         }
         for (int jsub = 0; jsub < NBO / NB; ++jsub) {
             const int64_t d = K * (NBO / NB) + jsub;
-            int64_t blocks = 1, tiles = 0;
+            int64_t blocks = 0, tiles = 0;
             for (int i = 0; i < n; ++i) {
                 if (st.v[i] < 0) continue;
                 int64_t rows1 = st.v[i] - (d + 1) * NB;
                 if (rows1 < 0) rows1 = 0;
-                const int64_t rows2 = B.it[i].r2_end - B.it[i].r2_begin;
+                const int64_t rows2 = r2e.v[i] - r2b.v[i];
                 const int64_t rows = rows1 + rows2;
                 if (rows > 0) blocks = std::max(blocks, (rows + PANEL_ROWS - 1) / PANEL_ROWS);
                 tiles = std::max(tiles, rows1 / NB + rows2 / NB);
             }
-            LAUNCH(k_panel, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, st, d, d_info);
+            LAUNCH(k_panel, dim3((unsigned)(blocks + 1), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, d, d_info); // + inverse workgroup
             const int64_t c_hi = K * (NBO / NB) + (NBO / NB - 1);
             if (jsub < NBO / NB - 1 && tiles > 0)
                 LAUNCH(k_upd64, dim3((unsigned)tiles, (unsigned)(c_hi - d), (unsigned)n), dim3(256), 0, s, B,
-                                   st, d, c_hi);
+                                   st, r2b, r2e, d, c_hi);
         }
         const int64_t c_first = k0 + NBO;
         int64_t T = 0;
@@ -825,7 +844,7 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
             if (st.v[i] < 0) continue;
             int64_t T1 = (st.v[i] - c_first) / TL;
             if (T1 < 0) T1 = 0;
-            const int64_t Ti = T1 + (B.it[i].r2_end - B.it[i].r2_begin) / TL;
+            const int64_t Ti = T1 + (r2e.v[i] - r2b.v[i]) / TL;
             T = std::max(T, Ti);
             flops += (double)(Ti * (Ti + 1) / 2) * (double)TL * (double)TL * (double)NBO * 2.0;
         }
@@ -834,10 +853,10 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
         if (timed) hipEventRecord(prof->ev[2 * prof->n], s);
         if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
             const int64_t T64 = 2 * T;
-            LAUNCH(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
+            LAUNCH(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, k0,
                                c_first);
         } else if (T > 0) {
-            LAUNCH(k_trail, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, k0,
+            LAUNCH(k_trail, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, k0,
                                c_first);
         }
         if (timed) hipEventRecord(prof->ev[2 * prof->n + 1], s), ++prof->n;
@@ -850,7 +869,6 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
-    LAUNCH(k_dinv, dim3((unsigned)(nout * (NBO / NB)), 1, (unsigned)n), dim3(256), 0, s, B);
     for (int64_t t = 0; t < nout; ++t) {
         CholStep Kst, cbeg;
         int64_t blocks = 1;
@@ -881,7 +899,9 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
 {
     CholBatch B{};
     B.it[0] = CholItem{ A, w, y, x, dinv, ld, ld, ld, ld };
-    CholHostItem H{ row_end, col_begin };
+    CholHostItem H;
+    H.row_end = row_end;
+    H.col_begin = col_begin;
     chol_factor(s, B, 1, &H, d_info, prof);
     chol_bwd(s, B, 1, &H, prof);
     LAUNCH(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
@@ -898,59 +918,86 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
 // same as one Cholesky of a re-ordered matrix; the dependency chain is n / P + sepw (P - 1) pivots instead of n.
 // No atomics and a fixed summation order: results are bit-reproducible.
 
-// Level set-up in one launch.  blockIdx.z < P: one workgroup per local row of chunk z's matrix.  blockIdx.z == P: one
-// workgroup per row of the separator system Cs (block diagonal part from S, ws from rhs); only its block tridiagonal
-// band is ever written by the factorisation (and read by a child plan's gather), everything outside it stays the
-// zero it was allocated with.
+// Level set-up in one launch.  blockIdx.z < P: chunk z's matrix, GATHER_ROWS local rows per workgroup (one workgroup
+// per row made the launch dispatch-bound: 17 k workgroups at the first level of C3), then the workgroups that transpose
+// the coupling block with the separator above.  blockIdx.z == P: the rows of the separator system Cs (block diagonal part
+// from S, ws from rhs); only its block tridiagonal band is ever written by the factorisation (and read by a child
+// plan's gather), everything outside it stays the zero it was allocated with.
+#define GATHER_ROWS 8
 __global__ __launch_bounds__(256) void k_level_gather(const double* __restrict__ S, int64_t ld, const double* __restrict__ rhs,
                                                       const int64_t* __restrict__ env_col, const CholBatch B,
                                                       const CholStep first, int64_t sepw, int P,
                                                       const int64_t* __restrict__ sep_start, double* __restrict__ Cs,
-                                                      int64_t lds, double* __restrict__ ws)
+                                                      int64_t lds, double* __restrict__ ws, int64_t tile0)
 {
     const int z = blockIdx.z;
-    const int64_t i = blockIdx.x;
     if (z == P) {
-        if (i >= lds) return;
-        const int64_t c = i / sepw, u = i - c * sepw;
-        const int64_t g = sep_start[c] + u;
-        double* dst = Cs + i * lds;
-        const int64_t j0 = c > 0 ? (c - 1) * sepw : 0, j1 = (c + 1) * sepw; // lower part of the band
-        for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
-            int64_t cj = j / sepw, v = j - cj * sepw;
-            dst[j] = (cj == c && v <= u) ? S[g * ld + sep_start[c] + v] : 0.0;
+        for (int rr = 0; rr < GATHER_ROWS; ++rr) {
+            const int64_t i = (int64_t)blockIdx.x * GATHER_ROWS + rr;
+            if (i >= lds) return;
+            const int64_t c = i / sepw, u = i - c * sepw;
+            const int64_t g = sep_start[c] + u;
+            double* dst = Cs + i * lds;
+            const int64_t j0 = c > 0 ? (c - 1) * sepw : 0, j1 = (c + 1) * sepw; // lower part of the band
+            for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+                int64_t cj = j / sepw, v = j - cj * sepw;
+                dst[j] = (cj == c && v <= u) ? S[g * ld + sep_start[c] + v] : 0.0;
+            }
+            if (threadIdx.x == 0) ws[i] = rhs[g];
         }
-        if (threadIdx.x == 0) ws[i] = rhs[g];
         return;
     }
     const int64_t ldc = B.it[z].ld, nc = B.it[z].ncols, a = first.v[z];
-    if (i >= ldc) return;
     const bool has_top = z > 0, has_bot = z < P - 1;
-    double* __restrict__ wc = B.it[z].w;
-    double* dst = B.it[z].A + i * ldc;
-    if (i < nc) {
-        const int64_t g = a + i;
-        int64_t c0 = env_col[g / 128] - a;
-        if (c0 < 0) c0 = 0;
-        const int64_t c1 = 128 * (i / 128 + 1); // end of this row's skyline segment (tile aligned, <= nc)
-        const double* src = S + g * ld + a;
-        for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) dst[j] = src[j];
-        if (threadIdx.x == 0) wc[i] = rhs[g];
+    if ((int64_t)blockIdx.x >= tile0) {
+        // 64 x 64 tile (tr, tc) of the coupling block S[a .. a + jn, a - sepw .. a) with the separator above: read by rows,
+        // written transposed into the border rows nc + 64 tc .. of the chunk matrix
+        __shared__ double sTile[64][65];
+        const int64_t jn = nc < sepw ? nc : sepw, nt_r = jn / 64, tt = (int64_t)blockIdx.x - tile0;
+        if (!has_top || tt >= nt_r * (sepw / 64)) return;
+        const int64_t tr = tt % nt_r, tc = tt / nt_r;
+        const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+        const double* src = S + (a + 64 * tr + r) * ld + (a - sepw + 64 * tc) + c0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sTile[r][c0 + c] = src[c];
+        __syncthreads();
+        double* out = B.it[z].A + (nc + 64 * tc + r) * ldc + 64 * tr + c0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) out[c] = sTile[c0 + c][r];
         return;
     }
-    const int64_t u2 = i - nc; // border row: [0, sepw) separator above, [sepw, 2 sepw) separator below
-    if (u2 < sepw) {
-        const int64_t g = a - sepw + u2; // column g of the rows below it (the coupling lives in S[a + j][g])
-        const int64_t jn = nc < 2 * sepw ? nc : 2 * sepw;
-        for (int64_t j = threadIdx.x; j < ldc; j += 256)
-            dst[j] = (has_top && j < jn) ? S[(a + j) * ld + g] : 0.0;
-    } else {
-        const int64_t g = a + nc + (u2 - sepw);
-        const int64_t j0 = nc > 2 * sepw ? nc - 2 * sepw : 0;
-        for (int64_t j = threadIdx.x; j < ldc; j += 256)
-            dst[j] = (has_bot && j >= j0 && j < nc) ? S[g * ld + a + j] : 0.0;
+    double* __restrict__ wc = B.it[z].w;
+    for (int rr = 0; rr < GATHER_ROWS; ++rr) {
+        const int64_t i = (int64_t)blockIdx.x * GATHER_ROWS + rr;
+        if (i >= ldc) return;
+        double* dst = B.it[z].A + i * ldc;
+        if (i < nc) {
+            const int64_t g = a + i;
+            int64_t c0 = env_col[g / 128] - a;
+            if (c0 < 0) c0 = 0;
+            const int64_t c1 = 128 * (i / 128 + 1); // end of this row's skyline segment (tile aligned, <= nc)
+            const double* src = S + g * ld + a;
+            for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) dst[j] = src[j];
+            if (threadIdx.x == 0) wc[i] = rhs[g];
+            continue;
+        }
+        // border row: [0, sepw) separator above, [sepw, 2 sepw) separator below.  Columns of the border block right of the
+        // row's own 128-tile are never touched (the trailing updates work on the lower tile triangle).
+        const int64_t u2 = i - nc;
+        const int64_t jend = nc + 128 * (u2 / 128 + 1);
+        if (u2 < sepw) {
+            // the coupling with the separator above lives in S[a + j][a - sepw + u2], j < sepw (the separator is at least
+            // one bandwidth wide): a TRANSPOSED block, copied by the tile workgroups; this row only clears the rest
+            const int64_t jn = has_top ? (nc < sepw ? nc : sepw) : 0;
+            for (int64_t j = jn + threadIdx.x; j < jend; j += 256) dst[j] = 0.0;
+        } else {
+            const int64_t g = a + nc + (u2 - sepw);
+            const int64_t j0 = nc > 2 * sepw ? nc - 2 * sepw : 0;
+            for (int64_t j = threadIdx.x; j < jend; j += 256)
+                dst[j] = (has_bot && j >= j0 && j < nc) ? S[g * ld + a + j] : 0.0;
+        }
+        if (threadIdx.x == 0) wc[i] = 0.0;
     }
-    if (threadIdx.x == 0) wc[i] = 0.0;
 }
 
 // Add the chunks' border blocks (-Y Y^T) and border right-hand sides into the separator system: one workgroup per
@@ -1001,43 +1048,55 @@ __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, in
 }
 
 // the level's solution: chunk interiors (blockIdx.z < P) and separator variables (blockIdx.z == P)
+// (finite: the top level's scatter also is the reference's allFinite check of the solution, :1912-1913; NULL below it)
 __global__ __launch_bounds__(256) void k_level_scatter(const CholBatch B, const CholStep first, int P, int64_t sepw,
                                                        const int64_t* __restrict__ sep_start, const double* __restrict__ xs,
-                                                       int64_t lds, double* __restrict__ x)
+                                                       int64_t lds, double* __restrict__ x, int* __restrict__ finite)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
     if ((int)blockIdx.z == P) {
-        if (j < lds) x[sep_start[j / sepw] + j % sepw] = xs[j];
-        return;
+        if (j < lds) x[sep_start[j / sepw] + j % sepw] = v = xs[j];
+    } else if (j < B.it[blockIdx.z].ncols) {
+        x[first.v[blockIdx.z] + j] = v = B.it[blockIdx.z].x[j];
     }
-    if (j < B.it[blockIdx.z].ncols) x[first.v[blockIdx.z] + j] = B.it[blockIdx.z].x[j];
+    if (finite && !isfinite(v)) atomicOr(finite, 4);
 }
 
 static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs, double* x,
-                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof)
+                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, bool top)
 {
     const int P = pl.P;
     const int64_t sepw = pl.sepw, lds = pl.lds;
     CholBatch B{}, Bs{};
     CholStep first;
-    CholHostItem H[SRK_MAX_CHUNKS], Hs{ pl.s_row_end.data(), pl.s_col_begin.data() };
+    CholHostItem H[SRK_MAX_CHUNKS], Hs;
+    Hs.row_end = pl.s_row_end.data();
+    Hs.col_begin = pl.s_col_begin.data();
     int64_t max_ldc = 0, max_nc = 0;
     for (int c = 0; c < SRK_MAX_CHUNKS; ++c) first.v[c] = 0;
     for (int c = 0; c < P; ++c) {
         B.it[c] = CholItem{ pl.Ac[c], pl.wc[c], pl.yc[c], pl.xc[c], pl.dinvc[c], pl.ldc[c], pl.n[c], pl.n[c], pl.ldc[c] };
-        H[c] = CholHostItem{ pl.row_end[c].data(), pl.col_begin[c].data() };
+        H[c].row_end = pl.row_end[c].data();
+        H[c].col_begin = pl.col_begin[c].data();
+        H[c].r2_split = pl.n[c] + sepw;
+        H[c].bot_first_col = pl.n[c] - sepw; // the separator below couples with the last sepw (>= bandwidth) columns only
+        H[c].has_top = c > 0;
+        H[c].has_bot = c < P - 1;
         first.v[c] = pl.a[c];
         max_ldc = std::max(max_ldc, pl.ldc[c]);
         max_nc = std::max(max_nc, pl.n[c]);
     }
     Bs.it[0] = CholItem{ pl.Cs, pl.ws, pl.ys, pl.xs, pl.dinvs, lds, lds, lds, lds };
 
-    LAUNCH(k_level_gather, dim3((unsigned)std::max(max_ldc, lds), 1, (unsigned)(P + 1)), dim3(256), 0, s, S, ld, rhs,
-           d_env_col, B, first, sepw, P, pl.d_sep_start, pl.Cs, lds, pl.ws);
+    // row workgroups (GATHER_ROWS rows each), then the (sepw / 64)^2 transposing tile workgroups of an item
+    const int64_t tile0 = (std::max(max_ldc, lds) + GATHER_ROWS - 1) / GATHER_ROWS;
+    LAUNCH(k_level_gather, dim3((unsigned)(tile0 + (sepw / 64) * (sepw / 64)), 1, (unsigned)(P + 1)), dim3(256), 0, s, S, ld,
+           rhs, d_env_col, B, first, sepw, P, pl.d_sep_start, pl.Cs, lds, pl.ws, tile0);
     chol_factor(s, B, P, H, d_info, prof);
     LAUNCH(k_sep_reduce, dim3((unsigned)lds), dim3(256), 0, s, B, sepw, pl.Cs, lds, pl.ws);
     if (pl.child) { // the separator system is block tridiagonal: chunk it again
-        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof);
+        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof, false);
     } else {
         chol_factor(s, Bs, 1, &Hs, d_info, prof);
         chol_bwd(s, Bs, 1, &Hs, prof);
@@ -1045,12 +1104,12 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
     LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
     chol_bwd(s, B, P, H, prof);
     LAUNCH(k_level_scatter, dim3((unsigned)((std::max(max_nc, lds) + 255) / 256), 1, (unsigned)(P + 1)), dim3(256), 0, s, B,
-           first, P, sepw, pl.d_sep_start, pl.xs, lds, x);
+           first, P, sepw, pl.d_sep_start, pl.xs, lds, x, top ? d_info : nullptr);
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
                             double* x, const int64_t* d_env_col, int* d_info, SrkSolveProf* prof)
 {
-    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof);
-    LAUNCH(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
+    // every variable of the system is a chunk or a separator variable of the top level: its scatter checks them all
+    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true);
 }
