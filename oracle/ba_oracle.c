@@ -1066,6 +1066,110 @@ void orc_apply_corrections(int64_t N, double* points, int32_t M, double* cam_R, 
     }
 }
 
+/* ---------------------------------------------------------------- finite-difference derivative checkers
+ * BA:895-1138 (GetFiniteDiffFirstPartialDeriv* / SecondPartialDeriv*), the patches BA:336-394 and AddDeltaToFrameInplace
+ * BA:94-120: the reference's debug-only validation of the closed-form derivatives (rough_rtol 0.2, log only).  Central
+ * differences of the reprojection error with ONE landmark and / or ONE frame replaced by a perturbed copy.  Frame
+ * variables are perturbed as the reference perturbs them: fx fy u0 v0 on K, T and W on the DIRECT pose (T += dT,
+ * R <- Rodrigues(dW) R, BA:59-92), then inverted back.  Test utility of the oracle only. */
+static double fd_error(double f0, int64_t N, const double* points, int32_t M, const double* cam_R, const double* cam_T,
+                       const double* K, int32_t shared_k, const int64_t* row_ptr, const int32_t* obs_frame,
+                       const double* obs_uv, int64_t pi, const double* dX /* NULL = no landmark patch */, int32_t fj,
+                       const double* dF /* [10], NULL = no frame patch */)
+{
+    double* P = (double*)malloc(sizeof(double) * (size_t)(3 * (N > 0 ? N : 1)));
+    double* R = (double*)malloc(sizeof(double) * (size_t)(9 * M));
+    double* T = (double*)malloc(sizeof(double) * (size_t)(3 * M));
+    double* Kf = (double*)malloc(sizeof(double) * (size_t)(9 * M));
+    memcpy(P, points, sizeof(double) * (size_t)(3 * N));
+    memcpy(R, cam_R, sizeof(double) * (size_t)(9 * M));
+    memcpy(T, cam_T, sizeof(double) * (size_t)(3 * M));
+    for (int32_t j = 0; j < M; ++j) memcpy(Kf + 9 * j, shared_k ? K : K + 9 * j, sizeof(double) * 9);
+    if (dX)
+        for (int v = 0; v < 3; ++v) P[3 * pi + v] += dX[v]; /* SalientPointPatch BA:336-360 */
+    if (dF) { /* FramePatch BA:362-394 via AddDeltaToFrameInplace BA:94-120 */
+        double* Kj = Kf + 9 * fj;
+        Kj[0] += dF[0]; Kj[4] += dF[1]; Kj[2] += dF[2]; Kj[5] += dF[3];
+        double Rd[9], Td[3], rot[9], Rn[9];
+        orc_se3_inv(R + 9 * fj, T + 3 * fj, Rd, Td);
+        Td[0] += dF[4]; Td[1] += dF[5]; Td[2] += dF[6];
+        double w[3] = { dF[7], dF[8], dF[9] };
+        if (orc_rot_from_axis_angle(w, rot)) mat3_mul(rot, Rd, Rn);
+        else memcpy(Rn, Rd, sizeof Rn);
+        orc_se3_inv(Rn, Td, R + 9 * fj, T + 3 * fj);
+    }
+    double e = orc_reproj_error(f0, N, P, M, R, T, Kf, 0, row_ptr, obs_frame, obs_uv, NULL);
+    free(P); free(R); free(T); free(Kf);
+    return e;
+}
+
+#define FD_ARGS f0, N, points, M, cam_R, cam_T, K, shared_k, row_ptr, obs_frame, obs_uv
+/* landmark pi: first derivatives d1[3] (BA:895-912) and second derivatives d2[3][3] (BA:914-946) */
+void orc_fd_point(double f0, int64_t N, const double* points, int32_t M, const double* cam_R, const double* cam_T,
+                  const double* K, int32_t shared_k, const int64_t* row_ptr, const int32_t* obs_frame,
+                  const double* obs_uv, int64_t pi, double eps, double* d1, double* d2)
+{
+    for (int v = 0; v < 3; ++v) {
+        double a[3] = { 0, 0, 0 }, b[3] = { 0, 0, 0 };
+        a[v] = -eps; b[v] = eps;
+        d1[v] = (fd_error(FD_ARGS, pi, b, 0, NULL) - fd_error(FD_ARGS, pi, a, 0, NULL)) / (2 * eps);
+    }
+    for (int v1 = 0; v1 < 3; ++v1)
+        for (int v2 = 0; v2 < 3; ++v2) {
+            double e[4];
+            const double s1[4] = { 1, 1, -1, -1 }, s2[4] = { 1, -1, 1, -1 };
+            for (int q = 0; q < 4; ++q) {
+                double dx[3] = { 0, 0, 0 };
+                dx[v1] += s1[q] * eps;
+                dx[v2] += s2[q] * eps;
+                e[q] = fd_error(FD_ARGS, pi, dx, 0, NULL);
+            }
+            d2[3 * v1 + v2] = (e[0] - e[1] - e[2] + e[3]) / (4 * eps * eps);
+        }
+}
+/* frame fj: first derivatives d1[10] (BA:948-1030) and second derivatives d2[10][10] (BA:1031-1086) */
+void orc_fd_frame(double f0, int64_t N, const double* points, int32_t M, const double* cam_R, const double* cam_T,
+                  const double* K, int32_t shared_k, const int64_t* row_ptr, const int32_t* obs_frame,
+                  const double* obs_uv, int32_t fj, double eps, double* d1, double* d2)
+{
+    for (int v = 0; v < 10; ++v) {
+        double a[10] = { 0 }, b[10] = { 0 };
+        a[v] = -eps; b[v] = eps;
+        d1[v] = (fd_error(FD_ARGS, 0, NULL, fj, b) - fd_error(FD_ARGS, 0, NULL, fj, a)) / (2 * eps);
+    }
+    for (int v1 = 0; v1 < 10; ++v1)
+        for (int v2 = 0; v2 < 10; ++v2) {
+            double e[4];
+            const double s1[4] = { 1, 1, -1, -1 }, s2[4] = { 1, -1, 1, -1 };
+            for (int q = 0; q < 4; ++q) {
+                double df[10] = { 0 };
+                df[v1] += s1[q] * eps;
+                df[v2] += s2[q] * eps;
+                e[q] = fd_error(FD_ARGS, 0, NULL, fj, df);
+            }
+            d2[10 * v1 + v2] = (e[0] - e[1] - e[2] + e[3]) / (4 * eps * eps);
+        }
+}
+/* landmark pi x frame fj: second derivatives d2[3][10] (BA:1088-1138) */
+void orc_fd_point_frame(double f0, int64_t N, const double* points, int32_t M, const double* cam_R,
+                        const double* cam_T, const double* K, int32_t shared_k, const int64_t* row_ptr,
+                        const int32_t* obs_frame, const double* obs_uv, int64_t pi, int32_t fj, double eps, double* d2)
+{
+    for (int pv = 0; pv < 3; ++pv)
+        for (int fv = 0; fv < 10; ++fv) {
+            double e[4];
+            const double s1[4] = { 1, 1, -1, -1 }, s2[4] = { 1, -1, 1, -1 };
+            for (int q = 0; q < 4; ++q) {
+                double dx[3] = { 0, 0, 0 }, df[10] = { 0 };
+                dx[pv] = s1[q] * eps;
+                df[fv] = s2[q] * eps;
+                e[q] = fd_error(FD_ARGS, pi, dx, fj, df);
+            }
+            d2[10 * pv + fv] = (e[0] - e[1] - e[2] + e[3]) / (4 * eps * eps);
+        }
+}
+#undef FD_ARGS
+
 /* ---------------------------------------------------------------- LM driver */
 
 const char* orc_status_string(int status)

@@ -204,6 +204,27 @@ def compute_inplace(f0, sc, allowed_err_change=None, max_hessian_factor=None, ma
     return rc, rep
 
 
+def fd_point(f0, sc, pi, eps=1e-5):
+    """finite-difference first [3] and second [3][3] derivatives of the error w.r.t. landmark pi (BA:895-946)"""
+    d1, d2 = np.zeros(3), np.zeros((3, 3))
+    lib().orc_fd_point(C.c_double(f0), *sc._args(), C.c_int64(pi), C.c_double(eps), _d(d1), _d(d2))
+    return d1, d2
+
+
+def fd_frame(f0, sc, fj, eps=1e-5):
+    """finite-difference first [10] and second [10][10] derivatives w.r.t. the variables of frame fj (BA:948-1086)"""
+    d1, d2 = np.zeros(10), np.zeros((10, 10))
+    lib().orc_fd_frame(C.c_double(f0), *sc._args(), C.c_int32(fj), C.c_double(eps), _d(d1), _d(d2))
+    return d1, d2
+
+
+def fd_point_frame(f0, sc, pi, fj, eps=1e-5):
+    """finite-difference mixed second derivatives [3][10] of landmark pi and frame fj (BA:1088-1138)"""
+    d2 = np.zeros((3, 10))
+    lib().orc_fd_point_frame(C.c_double(f0), *sc._args(), C.c_int64(pi), C.c_int32(fj), C.c_double(eps), _d(d2))
+    return d2
+
+
 def set_threads(n):
     """Baseline variant (iii) only: OpenMP threads of the derivative / Schur / QR-update / back-substitution loops
     (1 = the reference's sequential order, what every parity test uses)."""
