@@ -22,6 +22,13 @@ public:
         auto it = kv_.find(name);
         return it == kv_.end() ? def : std::atol(it->second.c_str());
     }
+    // gflags booleans: --name, --name=true|false|1|0, --noname
+    bool Bool(const std::string& name, bool def) const {
+        auto it = kv_.find(name);
+        if (it != kv_.end()) return !(it->second == "false" || it->second == "0" || it->second == "no");
+        if (kv_.find("no" + name) != kv_.end()) return false;
+        return def;
+    }
     std::string String(const std::string& name, const std::string& def) const {
         auto it = kv_.find(name);
         return it == kv_.end() ? def : it->second;

@@ -153,6 +153,8 @@ public:
     size_t NormalizedVarsCount() const { return VarsCount() - 7; }
     const std::string& OptimizationStatusString() const { return status_; }
     const srk_ba_report& Report() const { return report_; }
+    /// the C-ABI handle, for callers that also use the srk_mvf_* steps on the same device (the MVF driver)
+    srk_ba* Handle() const { return h_; }
 
 private:
     struct Flat {

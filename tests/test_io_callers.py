@@ -213,3 +213,38 @@ def test_cpp_adapter_mvf_call_contract(orc, tmp_path):
     assert out["iterations"] == out["iterations_c"]
     assert out["err_final"] == pytest.approx(out["err_final_c"], rel=1e-9)
     assert out["maxdiff"] < 1e-9
+
+
+@pytest.mark.gpu
+def test_demo_multi_view_factorization_cli(orc, tmp_path):
+    """The drop-in of demo-multi-view-factorization (reference flags, cpp_impl/demos/demo-multi-view-factorization.cpp:
+    351-370; frame loop :529-656; driver multi-view-factorization.cpp:255-397) with the reference flagfile's values:
+    two ground-truth frames, then frames integrated by srk_mvf_relative_motion / srk_mvf_estimate_depths, bundle
+    adjustment whenever the driver's score exceeds 1e-3 -- every such call (shared K, f0 = 1, threshold 1e-3) is
+    replayed through the CPU oracle on the scene the demo handed over and must give the same result."""
+    import glob
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "demos", "demo-multi-view-factorization")
+    if not os.path.exists(exe):
+        pytest.skip("demos not built")
+    prefix = str(tmp_path / "ba")
+    out, log = _run([exe, "--flagfile=" + os.path.join(ROOT, "demos", "flagfile-demo-multi-view-factorization.txt"),
+                     "--max_frames=9", "--ba_max_iterations=6", "--dump_ba_prefix=" + prefix], ROOT)
+    assert out["world_points"] == 81 * 41 and out["frames"] + out["failed_frames"] == 9
+    assert out["integrated_frames"] >= 5 and out["salient_points"] > 100
+    assert "anchored on f=" in log and "reconstructed_salient_points_count=" in log
+    calls = sorted(glob.glob(prefix + "_*_before.bin"))
+    assert len(calls) == out["ba_calls"] and out["ba_calls"] >= 1
+    its = atts = 0
+    for before in calls:
+        f0, so = _read_scene_dump(before, orc)
+        _, sg = _read_scene_dump(before.replace("_before", "_after"), orc)
+        assert f0 == 1.0 and so.shared_k == 1 and so.M >= 3
+        rc_o, rep_o = orc.compute_inplace(1.0, so, 1e-3, None, 6)
+        its += rep_o.iterations
+        atts += rep_o.attempts
+        scale = max(1.0, float(np.abs(so.points).max()))
+        assert np.abs(sg.points - so.points).max() < 1e-6 * scale
+        assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+        assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6 * scale
+    assert (out["ba_iterations"], out["ba_attempts"]) == (its, atts)
