@@ -263,9 +263,20 @@ def main():
         ba.set_schur_precision(True)
     if args.sequential_attempts:
         ba.set_speculation(False)
+    exchange = "none"
     if world > 1:
-        from surikatoko_amd.dist import make_allreduce_hook
-        ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
+        # N > 1: the library's own RCCL all-reduces on its streams (srk_ba_rccl_init; the unique id travels through
+        # torch.distributed, nothing else does).  SRK_BENCH_EXCHANGE=torch keeps the Python callback of round 1
+        # (torch.distributed.all_reduce with a host synchronisation on either side); the gloo rehearsal needs it.
+        if backend == "nccl" and os.environ.get("SRK_BENCH_EXCHANGE", "rccl") == "rccl":
+            ident = [ba.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            ba.rccl_init(ident[0], rank, world)
+            exchange = "native RCCL all-reduce on the library's streams"
+        else:
+            from surikatoko_amd.dist import make_allreduce_hook
+            ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
+            exchange = f"torch.distributed all_reduce callback ({backend})"
     assert ba.upload(spec.f0, shard, already_normalized=True)
     RCS_MODE = {"dense": 0, "skyline": 1, "chunks": 2}
     if args.rcs != "chunks":
@@ -476,6 +487,7 @@ def main():
                                    "outer LM iteration (with its rejected attempts) of one continuing run from the "
                                    "uploaded state",
                        "parallelism": f"landmark shards x{world}" if world > 1 else "single GPU",
+                       "exchange": exchange,
                        "points_per_rank": shard.N, "obs_per_rank": shard.O, "rcs_dim": 10 * M - 7,
                        "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks,
                        "lm_attempts": "one attempt at a time (--sequential-attempts)" if args.sequential_attempts else

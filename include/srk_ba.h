@@ -101,6 +101,16 @@ int srk_ba_set_stream(srk_ba*, void* hip_stream);
  * ordered on that stream (or complete).  Returns 0 on success. */
 typedef int (*srk_allreduce_fn)(void* ctx, double* dev_ptr, int64_t count);
 int srk_ba_set_allreduce(srk_ba*, srk_allreduce_fn fn, void* ctx, int rank, int world_size);
+/* The same exchanges natively: RCCL all-reduces (sum, fp64) enqueued on the stream of the LM attempt that needs them,
+ * with no host synchronisation and no Python -- what a C++ caller on the 8 GPUs of a node uses (one process or thread
+ * per GPU, one handle each).  librccl.so is opened on first use.
+ *   srk_ba_rccl_get_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by any means;
+ *   srk_ba_rccl_init:          every rank creates the communicator on its handle's device (collective call);
+ *   srk_ba_rccl_set_comm:      use a communicator (ncclComm_t) the caller owns instead; NULL detaches.
+ * Either replaces a callback set with srk_ba_set_allreduce.  Call before srk_ba_upload_scene. */
+int srk_ba_rccl_get_unique_id(void* id128 /* out: 128 bytes */);
+int srk_ba_rccl_init(srk_ba*, const void* id128, int rank, int world_size);
+int srk_ba_rccl_set_comm(srk_ba*, void* nccl_comm, int rank, int world_size);
 
 /* ---- the reference API, one call ---- */
 int srk_ba_compute_inplace(srk_ba*, double f0,

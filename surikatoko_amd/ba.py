@@ -329,6 +329,20 @@ class BundleAdjustmentKanatani:
         self._hook = hook
         self._raise(self._lib.srk_ba_set_allreduce(C.c_void_p(self._h), hook, None, int(rank), int(world)))
 
+    # native RCCL exchange (include/srk_ba.h): no Python in the data path
+    def rccl_unique_id(self):
+        """128 bytes of a fresh ncclUniqueId (rank 0 calls this and hands the bytes to the other ranks)."""
+        buf = (C.c_ubyte * 128)()
+        self._raise(self._lib.srk_ba_rccl_get_unique_id(buf))
+        return bytes(buf)
+
+    def rccl_init(self, unique_id, rank, world):
+        """Collective: every rank creates the communicator on its handle's device; replaces an all-reduce callback."""
+        assert len(unique_id) == 128
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._raise(self._lib.srk_ba_rccl_init(C.c_void_p(self._h), buf, C.c_int(int(rank)), C.c_int(int(world))))
+        self._hook = None
+
     def phase_error(self):
         e, seen = C.c_double(0), C.c_int64(0)
         self._raise(self._lib.srk_ba_phase_error(C.c_void_p(self._h), C.byref(e), C.byref(seen)))

@@ -9,6 +9,9 @@
 #include "srk_dev.hpp"
 #include "srk_geom.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <chrono>
 #include <numeric>
@@ -95,6 +98,10 @@ struct srk_ba {
     srk_allreduce_fn allreduce = nullptr;
     void* allreduce_ctx = nullptr;
     int rank = 0, world = 1;
+    // native exchange: RCCL (librccl.so, loaded on first use) all-reduces on the stream of the attempt that needs them --
+    // no host round trip, no Python.  comm_owned: created by srk_ba_rccl_init (destroyed with the handle).
+    ncclComm_t comm = nullptr;
+    bool comm_owned = false;
     int64_t seen_global = -1; // observation count over all ranks of the uploaded scene (-1 = not yet exchanged)
 
     // timing
@@ -110,6 +117,38 @@ struct srk_ba {
     // re-zero every slot's system and plan buffers (clear_poison) before anything is computed from them.
     bool poisoned = false;
 };
+
+// librccl.so is opened on first use: the library itself carries no link-time dependency on it (a single-GPU caller
+// never needs it), and a Python caller keeps torch's own copy to itself
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char* n : names)
+            if ((a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+        if (!a.lib) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.lib, "ncclAllReduce"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+} // namespace
 
 #define HIPCHK(h, expr)                                                                              \
     do {                                                                                             \
@@ -207,6 +246,7 @@ void srk_ba_destroy(srk_ba* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->att[1].stream) hipStreamSynchronize(h->att[1].stream);
+    if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
     DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->pts[2], &h->camR[0], &h->camR[1], &h->camR[2], &h->camT[0], &h->camT[1],
                       &h->camT[2], &h->K, &h->cam[0], &h->cam[1], &h->cam[2], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
@@ -267,6 +307,44 @@ int srk_ba_set_allreduce(srk_ba* h, srk_allreduce_fn fn, void* ctx, int rank, in
     h->world = world_size;
     h->seen_global = -1;
     return SRK_OK;
+}
+
+// ---- native RCCL exchange
+int srk_ba_rccl_get_unique_id(void* id128)
+{
+    if (!id128 || !rccl().ok) return SRK_E_DEVICE;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+    return rccl().GetUniqueId(reinterpret_cast<ncclUniqueId*>(id128)) == ncclSuccess ? SRK_OK : SRK_E_DEVICE;
+}
+static int rccl_attach(srk_ba* h, ncclComm_t comm, bool owned, int rank, int world_size)
+{
+    if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
+    h->comm = comm;
+    h->comm_owned = owned;
+    h->allreduce = nullptr;
+    h->allreduce_ctx = nullptr;
+    h->rank = rank;
+    h->world = world_size;
+    h->seen_global = -1;
+    return SRK_OK;
+}
+int srk_ba_rccl_init(srk_ba* h, const void* id128, int rank, int world_size)
+{
+    if (!h || !id128 || world_size < 1 || rank < 0 || rank >= world_size) return SRK_E_ARGS;
+    if (!rccl().ok) { h->last_error = "librccl.so could not be loaded"; return SRK_E_DEVICE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = rccl().CommInitRank(&comm, world_size, id, rank);
+    if (r != ncclSuccess) { h->last_error = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r); return SRK_E_DEVICE; }
+    return rccl_attach(h, comm, true, rank, world_size);
+}
+int srk_ba_rccl_set_comm(srk_ba* h, void* nccl_comm, int rank, int world_size)
+{
+    if (!h || world_size < 1 || rank < 0 || rank >= world_size) return SRK_E_ARGS;
+    if (nccl_comm && !rccl().ok) { h->last_error = "librccl.so could not be loaded"; return SRK_E_DEVICE; }
+    return rccl_attach(h, reinterpret_cast<ncclComm_t>(nccl_comm), false, rank, world_size);
 }
 
 // ------------------------------------------------------------------ host normalisation (bundle-adj-kanatani.cpp:123-333)
@@ -900,7 +978,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     // covisibility of THIS shard; with several ranks the caller must supply the global one
     // (srk_ba_set_covisibility) -- until then the skyline is the full lower triangle
     h->min_cv.assign((size_t)M, 0);
-    if (!h->allreduce) {
+    if (!h->allreduce && !h->comm) {
         for (int32_t j = 0; j < M; ++j) h->min_cv[(size_t)j] = j;
         for (int64_t i = 0; i < N; ++i) {
             if (row_ptr[i + 1] == row_ptr[i]) continue;
@@ -978,6 +1056,14 @@ extern "C" int srk_ba_download_scene(srk_ba* h, double* pts, double* cam_R, doub
 
 static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
 {
+    if (h->comm) { // RCCL on this attempt's stream: ordered behind the kernels that filled the buffer, nothing waits on the host
+        ncclResult_t r = rccl().AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) {
+            h->last_error = std::string("ncclAllReduce: ") + rccl().GetErrorString(r);
+            return SRK_E_DEVICE;
+        }
+        return SRK_OK;
+    }
     if (!h->allreduce) return SRK_OK;
     // the hook reduces on its own (RCCL) stream: everything queued on ours must have landed first, and the hook
     // returns only after the reduced values are visible
@@ -1057,7 +1143,7 @@ static int phase_schur(srk_ba* h, double c)
     // before the exchange; the identity diagonal of fixed / padding variables comes from rank 0 alone
     srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->A->S), P<double>(h->A->rhs), h->rank == 0 ? 1.0 : 0.0);
     HIPCHK(h, hipGetLastError());
-    if (h->allreduce) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
+    if (h->allreduce || h->comm) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
         int rc;
         if ((rc = dev_alloc(h, h->A->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
         double* tail = P<double>(h->A->packed) + h->band_packed;
@@ -1246,7 +1332,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     // once per uploaded scene: it does not change between optimise calls
     if (h->seen_global < 0) {
         double seen_d = (double)d.O;
-        if (h->allreduce) {
+        if (h->allreduce || h->comm) {
             HIPCHK(h, hipMemcpyAsync(h->A->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
             int rc = exchange(h, P<double>(h->A->err_out), 1);
             if (rc != SRK_OK) return fail_device(rc);
@@ -1371,7 +1457,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         // several ranks: one attempt at a time.  (Every rank takes the same decisions, so the two slots' exchanges would be
         // issued in the same order everywhere -- but that path has never run over RCCL on hardware: it stays off until
         // an N > 1 run has covered it.)
-        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0 && !h->allreduce;
+        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0 && !h->allreduce && !h->comm;
         bool spec_in_flight = false;
         int round = 0;
         const int64_t attempts_before = rep->attempts;
@@ -1388,7 +1474,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             // solves.  Several ranks: a Schur phase ends in a blocking exchange, so slot 0's solve is enqueued before it
             // and runs under slot 1's Schur sum and exchange.
             rc = enqueue_schur(0, hessian_factor);
-            if (h->allreduce) {
+            if (h->allreduce || h->comm) {
                 if (rc == SRK_OK) rc = enqueue_rest(0, hessian_factor);
                 if (rc == SRK_OK && speculate_now) rc = enqueue_schur(1, hessian_factor * 10);
             } else {

@@ -669,6 +669,32 @@ def test_c5_nested_dissection_agrees_with_single_chain(gpu):
 
 # ------------------------------------------------------------------ sharded path, world size 1 on the GPU
 
+def test_native_rccl_exchange_world_size_1(orc):
+    """The library's own RCCL path (srk_ba_rccl_get_unique_id / srk_ba_rccl_init, librccl.so opened on first use,
+    ncclAllReduce on the attempt's stream, no host synchronisation) at world size 1 -- all one GPU can run: the packed
+    band, the right-hand side and the {error, status} words go through ncclAllReduce and come back unchanged, so the
+    run must equal the oracle's like any single-GPU run."""
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        ba.rccl_init(ba.rccl_unique_id(), 0, 1)
+        so = _orc_scene(orc, sc)
+        rc_o, rep_o = orc.compute_inplace(spec.f0, so, 1e-7, 1e6, 40)
+        crit = sa.BundleAdjustmentKanataniTermCriteria()
+        crit.AllowedReprojErrRelativeChange(1e-7)
+        crit.MaxHessianFactor(1e6)
+        sg = sc.copy()
+        ok = ba.ComputeInplace(spec.f0, sg, crit, 40)
+        rep = ba.report
+        assert ok == (rc_o == 0) and sa.status_string(rep.status) == orc.status_string(rep_o.status)
+        assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+        assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+        assert np.abs(sg.points - so.points).max() < 1e-6
+    finally:
+        ba.close()
+
+
 def test_allreduce_hook_with_device_pointers(orc, gpu):
     """The RCCL path end to end at world size 1: the library packs the skyline, calls the torch.distributed hook with
     DEVICE pointers (zero-copy __cuda_array_interface__ views) and must give the same iterations as without it."""
