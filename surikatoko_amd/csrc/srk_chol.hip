@@ -290,8 +290,10 @@ __device__ __forceinline__ void tile_inverse(const double (*sL)[NB + 2], double 
 #ifdef SRK_PANEL_STAMPS
 __device__ long long g_panel_stamps[16];
 #define STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d == 40) g_panel_stamps[k] = wall_clock64(); } while (0)
+#define STAMPI(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && d == 40) g_panel_stamps[k] = wall_clock64(); } while (0) // inverse workgroup
 #else
 #define STAMP(k)
+#define STAMPI(k)
 #endif
 #define PANEL_ROWS 63 // matrix rows per workgroup; the 64th quad carries the right-hand side as one more row
 __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     const int64_t k0 = d * NB;
     double* Ab = A + k0 * ld + k0;
     STAMP(0);
+    STAMPI(10);
     {
         // row i = t >> 2, 16 columns from (t & 3) * 16: eight independent 16-byte loads per thread; entries above the
         // diagonal are masked by select (never branched on)
@@ -340,18 +343,6 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     }
     __syncthreads();
     STAMP(1);
-    bool bad = potrf64(sD, sCol, sDiag, sInv);
-    STAMP(2);
-    if (bad && inv_wg && threadIdx.x == 0) atomicOr(info, 1);
-    // The factored tile is never stored back into A: the other workgroups of this launch read the unfactored tile from
-    // A when they start, and nothing orders their start before such a store -- a grid larger than the chip, or a GPU
-    // shared with other processes, starts some of them late.  No later kernel reads a diagonal tile of A or L_dd itself:
-    // the backward substitution works with the inverse, which goes to this tile's slot of the Dinv buffer.
-    if (inv_wg && blocks > 0) {
-        tile_inverse(sD, sZ, sT, sDiag, B.it[blockIdx.z].dinv + d * NB * NB);
-        return;
-    }
-    STAMP(3);
     // Row sweep X = A[rows, panel] L_dd^-T, four columns at a time.  A row is split over the 4 lanes of a quad (lane q
     // owns columns c = 4m + q).  Quad 63 carries the right-hand side w_d as one more row: its sweep IS the forward
     // substitution y_d = L_dd^-1 w_d, at no extra latency.
@@ -370,9 +361,21 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = row[4 * m + q];
-#ifdef SRK_PANEL_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    // (issued before the tile is factored: the loads' latency, ~1.5 us after the factorisation, hides under it)
+    bool bad = potrf64(sD, sCol, sDiag, sInv);
+    STAMP(2);
+    if (bad && inv_wg && threadIdx.x == 0) atomicOr(info, 1);
+    // The factored tile is never stored back into A: the other workgroups of this launch read the unfactored tile from
+    // A when they start, and nothing orders their start before such a store -- a grid larger than the chip, or a GPU
+    // shared with other processes, starts some of them late.  No later kernel reads a diagonal tile of A or L_dd itself:
+    // the backward substitution works with the inverse, which goes to this tile's slot of the Dinv buffer.
+    if (inv_wg && blocks > 0) {
+        STAMPI(11);
+        tile_inverse(sD, sZ, sT, sDiag, B.it[blockIdx.z].dinv + d * NB * NB);
+        STAMPI(12);
+        return;
+    }
+    STAMP(3);
     STAMP(4);
 #pragma unroll
     for (int b = 0; b < 16; ++b) {

@@ -21,5 +21,6 @@ print("wall_clock64 ticks (100 MHz => x10 ns); note: the stamps themselves pertu
 for n,a,b in zip(names,t[:-1],t[1:]): print(f"  {n:12s} {b-a:8d} ticks = {(b-a)*10/1000:.2f} us")
 print("  sweep quarters:", out[7]-out[4], out[8]-out[7], out[9]-out[8], out[5]-out[9])
 print("  total", (t[-1]-t[0])*10/1000, "us")
+print("inverse workgroup: load + potrf %.2f us, inverse %.2f us, total %.2f us" % ((out[11]-out[10])*10/1000, (out[12]-out[11])*10/1000, (out[12]-out[10])*10/1000))
 PY
 )
