@@ -41,6 +41,8 @@ def parse():
                     help="remove this fraction of the observations at random (ragged tracks; not the headline workload)")
     ap.add_argument("--schur-fp32", action="store_true",
                     help="opt-in mixed precision (fp32 run sums in the Schur kernel); never the headline configuration")
+    ap.add_argument("--store-f32", action="store_true",
+                    help="opt-in f32 storage of the point-frame blocks W (arithmetic stays fp64); never the headline configuration")
     ap.add_argument("--sequential-attempts", action="store_true",
                     help="one attempt slot (srk_ba_set_speculation off): kernels of different attempts never overlap, "
                          "so per-kernel durations under rocprofv3 are those of the kernel alone (profiles/)")
@@ -261,6 +263,8 @@ def main():
     ba.set_profile(0)  # the timed region carries no instrumentation; phases are timed in separate steps below
     if args.schur_fp32:
         ba.set_schur_precision(True)
+    if args.store_f32:
+        ba.set_storage_precision(True)
     if args.sequential_attempts:
         ba.set_speculation(False)
     exchange = "none"
@@ -479,7 +483,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if not args.schur_fp32 else "f64 with fp32 Schur run sums (opt-in mixed precision)",
+            "dtype": ("f64" if not args.schur_fp32 else "f64 with fp32 Schur run sums (opt-in mixed precision)") +
+                     (" / point-frame blocks stored as f32 (opt-in)" if args.store_f32 else ""),
             "data": "synthetic",
             "config": {"workload": (f"ragged tracks ({args.drop:.0%} of the observations dropped) of " if args.drop > 0 else "") +
                                    f"{args.config}: {M} cams / {N_total} pts / {O_total} obs (circle-grid, "

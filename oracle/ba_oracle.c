@@ -33,6 +33,10 @@ void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
 /* Timing hook of bench.py's cpu_baseline leg ONLY: skip the Householder QR of the reduced system (4/3 n^3 flops: hours
  * at n = 9993) and continue with zero camera corrections, so that the derivative, Schur and back-substitution passes of
  * the 1000-camera scene can be timed on the CPU.  Never set by a test; results are meaningless while it is on. */
+/* f32 storage mode of the HIP path (srk_ba_set_storage_precision): the point-frame blocks are rounded to float where the
+ * derivative pass stores them; everything computed from them afterwards sees the rounded values.  Off by default. */
+static int orc_w_f32 = 0;
+void orc_set_w_storage_f32(int on) { orc_w_f32 = on != 0; }
 static int orc_skip_solve = 0;
 void orc_set_skip_solve(int on) { orc_skip_solve = on != 0; }
 int orc_get_threads(void) { return orc_threads; }
@@ -785,6 +789,8 @@ void orc_derivatives(double f0, int64_t N, const double* points, int32_t M, cons
         }
     }
     csc_free(&c);
+    if (orc_w_f32)
+        for (int64_t e = 0; e < 30 * O; ++e) Wpf[e] = (double)(float)Wpf[e];
 }
 
 /* ---------------------------------------------------------------- gauge index map */

@@ -231,6 +231,11 @@ def set_threads(n):
     lib().orc_set_threads(C.c_int(int(n)))
 
 
+def set_w_storage_f32(on):
+    """Round the point-frame blocks to float where they are stored (the HIP path's f32 storage mode)."""
+    lib().orc_set_w_storage_f32(C.c_int(int(bool(on))))
+
+
 def set_skip_solve(on):
     """bench.py's cpu_baseline leg only: time derivatives + Schur + back-substitution without the dense QR."""
     lib().orc_set_skip_solve(C.c_int(int(bool(on))))

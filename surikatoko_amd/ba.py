@@ -288,6 +288,10 @@ class BundleAdjustmentKanatani:
     def jacobian_kernel(self):
         return int(self._lib.srk_ba_jacobian_kernel(C.c_void_p(self._h)))
 
+    def set_storage_precision(self, f32=False):
+        """W stored as float (next upload); arithmetic stays fp64 -- see include/srk_ba.h"""
+        self._raise(self._lib.srk_ba_set_storage_precision(C.c_void_p(self._h), C.c_int(int(bool(f32)))))
+
     def set_schur_precision(self, fp32=False):
         """Opt-in mixed precision: fp32 run sums in the grouped Schur kernel (everything else stays fp64)."""
         self._raise(self._lib.srk_ba_set_schur_precision(C.c_void_p(self._h), C.c_int(int(bool(fp32)))))

@@ -108,6 +108,7 @@ struct srk_ba {
     hipEvent_t ev[16]{};
     std::vector<hipEvent_t> chol_ev;
     bool schur_fp32 = false; // opt-in mixed precision: fp32 run sums in the grouped Schur kernel
+    bool store_f32 = false;  // opt-in: the point-frame blocks W are STORED as float (next upload); arithmetic stays fp64
     int profile_level = 0; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
     int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
@@ -779,6 +780,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     if (d.Ns == 0) d.Ns = 64;
     d.ld = ((10 * (int64_t)M + SRK_CHOL_NB - 1) / SRK_CHOL_NB) * SRK_CHOL_NB;
     d.comp = 1;
+    d.w_f32 = h->store_f32 ? 1 : 0;
     h->d = d;
     h->f0 = f0;
 
@@ -897,7 +899,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->col_ptr, 8 * ((int64_t)M + 1));
     ALLOC(h->fobs_pt, 4 * O);
     ALLOC(h->fobs_uv, 16 * O);
-    ALLOC(h->W, 8 * 30 * d.Os);
+    ALLOC(h->W, (d.w_f32 ? 4 : 8) * 30 * d.Os);
     ALLOC(h->Vg, 8 * 9 * d.Ns);
     ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
     select_attempt(h, 0);
@@ -1911,7 +1913,11 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     }
     case SRK_BUF_POINT_FRAME: {
         std::vector<double> w((size_t)(30 * d.Os));
-        if ((rc = d2h(w.data(), h->W.p, w.size() * 8)) != SRK_OK) return rc;
+        if (d.w_f32) {
+            std::vector<float> wf((size_t)(30 * d.Os));
+            if ((rc = d2h(wf.data(), h->W.p, wf.size() * 4)) != SRK_OK) return rc;
+            for (size_t i = 0; i < wf.size(); ++i) w[i] = (double)wf[i];
+        } else if ((rc = d2h(w.data(), h->W.p, w.size() * 8)) != SRK_OK) return rc;
         for (int64_t i = 0; i < d.N; ++i) {
             int64_t oi = h->row_ptr_int[(size_t)i], ou = h->row_ptr_user[(size_t)h->perm[(size_t)i]];
             int64_t cnt = h->row_ptr_int[(size_t)i + 1] - oi;
@@ -2058,6 +2064,16 @@ int srk_ba_set_jacobian_mode(srk_ba* h, int mode)
     return SRK_OK;
 }
 int srk_ba_jacobian_kernel(srk_ba* h) { return (h && h->have_scene) ? (h->jac_runs ? 2 : (h->jac_fused ? 1 : 0)) : -1; }
+
+// 0 = everything stored in fp64 (default, the reference's Scalar = double); 1 = the point-frame blocks W -- 240 of the
+// 260 bytes per observation the derivative kernel writes and the Schur and back-substitution kernels read -- are stored
+// as float and widened on load; every sum, the reduced camera system and the solve stay fp64.  Next upload.
+int srk_ba_set_storage_precision(srk_ba* h, int f32)
+{
+    if (!h || (f32 != 0 && f32 != 1)) return SRK_E_ARGS;
+    h->store_f32 = f32 != 0;
+    return SRK_OK;
+}
 
 int srk_ba_set_schur_precision(srk_ba* h, int fp32)
 {

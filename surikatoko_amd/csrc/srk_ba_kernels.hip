@@ -130,11 +130,12 @@ __device__ __forceinline__ void frame_ab(const double* __restrict__ c, const Obs
 // One thread per observation.  Writes the 3x10 point-frame block (SoA, lane-contiguous 8-byte stores) and
 // reduces the point block V (6 unique) + point gradient (3) over the landmark's observations with a
 // wavefront segmented reduction; one atomic per (wave, landmark) segment.
+template <typename WT> // storage type of the point-frame blocks W: double, or float (srk_ba_set_storage_precision)
 __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __restrict__ pts,
                                                     const double* __restrict__ cam,
                                                     const int32_t* __restrict__ obs_frame,
                                                     const int32_t* __restrict__ obs_pt,
-                                                    const double* __restrict__ obs_uv, double* __restrict__ W,
+                                                    const double* __restrict__ obs_uv, WT* __restrict__ W,
                                                     double* __restrict__ Vg)
 {
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __r
         for (int pv = 0; pv < 3; ++pv)
 #pragma unroll
             for (int fv = 0; fv < 10; ++fv)
-                W[(int64_t)(10 * pv + fv) * d.Os + o] = (Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]) * g.s2;
+                W[(int64_t)(10 * pv + fv) * d.Os + o] = (WT)((Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]) * g.s2);
         acc[0] = (Ap[0] * Ap[0] + Bp[0] * Bp[0]) * g.s2;
         acc[1] = (Ap[0] * Ap[1] + Bp[0] * Bp[1]) * g.s2;
         acc[2] = (Ap[0] * Ap[2] + Bp[0] * Bp[2]) * g.s2;
@@ -209,11 +210,12 @@ __device__ __forceinline__ double jf_rcp(double d)
     return r;
 }
 
+template <typename WT>
 __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __restrict__ pts,
                                                    const double* __restrict__ cam,
                                                    const int32_t* __restrict__ obs_frame,
                                                    const int32_t* __restrict__ obs_pt,
-                                                   const double* __restrict__ obs_uv, double* __restrict__ W,
+                                                   const double* __restrict__ obs_uv, WT* __restrict__ W,
                                                    double* __restrict__ Vg, double* __restrict__ Ug,
                                                    const int32_t* __restrict__ wg_jmin)
 {
@@ -292,12 +294,12 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
             for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * s2; Bps[v] = Bp[v] * s2; }
 #pragma unroll
             for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * s2; Bfs[v] = Bf[v] * s2; }
-            double* wp = W + o;
+            WT* wp = W + o;
 #pragma unroll
             for (int pv = 0; pv < 3; ++pv)
 #pragma unroll
                 for (int fv = 0; fv < 10; ++fv) {
-                    *wp = Aps[pv] * Af[fv] + Bps[pv] * Bf[fv];
+                    *wp = (WT)(Aps[pv] * Af[fv] + Bps[pv] * Bf[fv]);
                     wp += d.Os;
                 }
             acc[0] = Aps[0] * Ap[0] + Bps[0] * Bp[0];
@@ -363,8 +365,12 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
 {
     if (d.O == 0) return;
     int64_t blocks = (d.O + SRK_JF_OBS - 1) / SRK_JF_OBS;
-    hipLaunchKernelGGL(k_jac_fused, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv, W,
-                       Vg, Ug, wg_jmin);
+    if (d.w_f32)
+        hipLaunchKernelGGL(k_jac_fused<float>, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
+                           reinterpret_cast<float*>(W), Vg, Ug, wg_jmin);
+    else
+        hipLaunchKernelGGL(k_jac_fused<double>, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
+                           W, Vg, Ug, wg_jmin);
 }
 
 // ------------------------------------------------------------------ K2 by runs: a lane keeps ONE frame for a whole task
@@ -390,11 +396,12 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
 // task (neighbouring pieces written together): +5 us.
 #define SRK_JR_RSTRIDE 66 // doubles between the 9 planes of the per-wave reduction scratch (64 lanes + bank skew)
 
+template <typename WT>
 __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __restrict__ pts,
                                                      const double* __restrict__ cam,
                                                      const int64_t* __restrict__ row_ptr,
                                                      const int32_t* __restrict__ obs_frame,
-                                                     const double* __restrict__ obs_uv, double* __restrict__ W,
+                                                     const double* __restrict__ obs_uv, WT* __restrict__ W,
                                                      double* __restrict__ Vg, double* __restrict__ Ug,
                                                      const int32_t* __restrict__ task_first,
                                                      const int32_t* __restrict__ task_count, int32_t n_tasks,
@@ -493,12 +500,12 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                 const double t0 = X0 - c[30], t1 = X1 - c[31], t2 = X2 - c[32];
                 Af[7] = a1[1] * t2 - a1[2] * t1; Af[8] = a1[2] * t0 - a1[0] * t2; Af[9] = a1[0] * t1 - a1[1] * t0;
                 Bf[7] = b1[1] * t2 - b1[2] * t1; Bf[8] = b1[2] * t0 - b1[0] * t2; Bf[9] = b1[0] * t1 - b1[1] * t0;
-                double* wp = W + o;
+                WT* wp = W + o;
 #pragma unroll
                 for (int pv = 0; pv < 3; ++pv)
 #pragma unroll
                     for (int fv = 0; fv < 10; ++fv) {
-                        *wp = Ap[pv] * Af[fv] + Bp[pv] * Bf[fv];
+                        *wp = (WT)(Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]);
                         wp += d.Os;
                     }
                 v9[0] = Ap[0] * Ap[0] + Bp[0] * Bp[0];
@@ -567,8 +574,13 @@ void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, con
                          int /* min_nf: shortest frame list of any task (not needed by this version) */)
 {
     if (n_tasks <= 0) return;
-    hipLaunchKernelGGL(k_jac_runs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame,
-                       obs_uv, W, Vg, Ug, task_first, task_count, n_tasks, wg_jmin);
+    const dim3 grid((unsigned)((n_tasks + 3) / 4));
+    if (d.w_f32)
+        hipLaunchKernelGGL(k_jac_runs<float>, grid, dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame, obs_uv,
+                           reinterpret_cast<float*>(W), Vg, Ug, task_first, task_count, n_tasks, wg_jmin);
+    else
+        hipLaunchKernelGGL(k_jac_runs<double>, grid, dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame, obs_uv, W, Vg, Ug,
+                           task_first, task_count, n_tasks, wg_jmin);
 }
 
 void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
@@ -577,8 +589,12 @@ void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, c
 {
     if (d.O == 0) return;
     int64_t blocks = (d.O + 255) / 256;
-    hipLaunchKernelGGL(k_jac_points, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
-                       W, Vg);
+    if (d.w_f32)
+        hipLaunchKernelGGL(k_jac_points<float>, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
+                           reinterpret_cast<float*>(W), Vg);
+    else
+        hipLaunchKernelGGL(k_jac_points<double>, dim3((unsigned)blocks), dim3(256), 0, s, d, pts, cam, obs_frame, obs_pt, obs_uv,
+                           W, Vg);
 }
 
 // ------------------------------------------------------------------ K2b: frame-major Jacobian pass
@@ -705,8 +721,9 @@ __device__ __forceinline__ bool point_block_inverse(const double* __restrict__ V
 // then the n_i(n_i+1)/2 lower 10x10 outer-product blocks are subtracted from S with fp64 atomics.
 #define SRK_SCH 32 // observations per LDS chunk
 
+template <typename WT>
 __global__ __launch_bounds__(256) void k_schur(SrkDims d, double c, const int64_t* __restrict__ row_ptr,
-                                               const int32_t* __restrict__ obs_frame, const double* __restrict__ W,
+                                               const int32_t* __restrict__ obs_frame, const WT* __restrict__ W,
                                                const double* __restrict__ Vg, double* __restrict__ S,
                                                double* __restrict__ rhs, const int32_t* __restrict__ pt_list,
                                                int64_t n_list)
@@ -782,8 +799,12 @@ void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* 
 {
     if (n_list <= 0) return;
     int64_t blocks = n_list < 65536 ? n_list : 65536;
-    hipLaunchKernelGGL(k_schur, dim3((unsigned)blocks), dim3(256), 0, s, d, c, row_ptr, obs_frame, W, Vg, S, rhs,
-                       pt_list, n_list);
+    if (d.w_f32)
+        hipLaunchKernelGGL(k_schur<float>, dim3((unsigned)blocks), dim3(256), 0, s, d, c, row_ptr, obs_frame,
+                           reinterpret_cast<const float*>(W), Vg, S, rhs, pt_list, n_list);
+    else
+        hipLaunchKernelGGL(k_schur<double>, dim3((unsigned)blocks), dim3(256), 0, s, d, c, row_ptr, obs_frame, W, Vg, S, rhs,
+                           pt_list, n_list);
 }
 
 // ------------------------------------------------------------------ K3g: Schur accumulation, grouped landmarks
@@ -859,10 +880,10 @@ __device__ __forceinline__ void schur_tile_update(float (&acc)[5][10], const flo
     }
 }
 
-template <int SLOTS, typename T>
+template <int SLOTS, typename T, typename WT>
 __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
-    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
+    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
     const int32_t* __restrict__ grp_frames, int nf_skip /* runs with at most this many frames belong to k_schur_mm / k_schur_ws */)
@@ -924,7 +945,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     // the round's PB nf consecutive observations (coalesced over q); LDS slot of (landmark q / nf, frame q % nf, k).
     // Everything per-thread is worked out here, once: the round loop below only adds the round's offset.
     const int qn = SRK_GRP_PB * nf;
-    const double* gp[SRK_GRP_PRE];
+    const WT* gp[SRK_GRP_PRE];
     int loff[SRK_GRP_PRE], koff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
 #pragma unroll
     for (int j = 0; j < SRK_GRP_PRE; ++j) {
@@ -1085,10 +1106,10 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
 // it stages round r + 1 into the second half of a double-buffered LDS arena (and already has round r + 2's global
 // loads in flight) while waves 0..6 multiply round r -- one barrier per round, the multiply never waits for memory.
 #define SRK_WS_NF 20
-template <typename T>
+template <typename T, typename WT>
 __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
-    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
+    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
     const int32_t* __restrict__ grp_frames)
@@ -1169,7 +1190,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
             const int nbn = np - pb < PB ? np - pb : PB;
             const int64_t oa = row_ptr[p0 + pb];
             nq_pre = (int)(row_ptr[p0 + pb + nbn] - oa);
-            const double* base = W + oa + lane;
+            const WT* base = W + oa + lane;
 #pragma unroll
             for (int k = 0; k < 30; ++k) {
                 pre[k][0] = lane < nq_pre ? base[(int64_t)k * d.Os] : 0.0;
@@ -1382,9 +1403,10 @@ __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS],
     load(a1, b1, 5); mac(a0, b0, 4);
     mac(a1, b1, 5);
 }
+template <typename WT>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
-    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const double* __restrict__ W,
+    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
     const int32_t* __restrict__ grp_frames)
@@ -1516,7 +1538,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
             nq_pre = sm < 3 ? rb - ra : 0;
             if (sq < nq_pre) {
-                const double* src = W + (int64_t)(10 * sm) * d.Os + o0 + ra + sq;
+                const WT* src = W + (int64_t)(10 * sm) * d.Os + o0 + ra + sq;
 #pragma unroll
                 for (int i = 0; i < 10; ++i) pre[i] = src[(int64_t)i * d.Os];
                 if (ragged)
@@ -1714,20 +1736,34 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
     static const bool env_valu = getenv("SRK_SCHUR_VALU") != nullptr; // development: the register-tile kernel k_schur_ws
     const bool no_ws = env_no_ws || fp32_accumulate;
     const int nf_skip = no_ws ? 0 : SRK_WS_NF;
-#define SRK_SCHUR_ARGS d, c, row_ptr, obs_pt, obs_slot, pt_mask, W, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames
+#define SRK_SCHUR_ARGS(WP) d, c, row_ptr, obs_pt, obs_slot, pt_mask, WP, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames
     const dim3 grid((unsigned)n_groups), block(SRK_GRP_THREADS);
+    const float* Wf = reinterpret_cast<const float*>(W);
+    // every kernel in two instantiations: W stored as double, or as float (srk_ba_set_storage_precision; loads widen)
+#define SRK_SCHUR_LAUNCH(KERNEL, BLOCK, ...)                                                                        \
+    do {                                                                                                            \
+        if (d.w_f32) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ float>), grid, BLOCK, 0, s, SRK_SCHUR_ARGS(Wf));        \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ double>), grid, BLOCK, 0, s, SRK_SCHUR_ARGS(W));               \
+    } while (0)
+#define SRK_SCHUR_LAUNCH_SKIP(KERNEL, ...)                                                                          \
+    do {                                                                                                            \
+        if (d.w_f32) hipLaunchKernelGGL((KERNEL<__VA_ARGS__ float>), grid, block, 0, s, SRK_SCHUR_ARGS(Wf), nf_skip); \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ double>), grid, block, 0, s, SRK_SCHUR_ARGS(W), nf_skip);       \
+    } while (0)
     if (!no_ws && n_wide + n_mid < n_groups) { // runs over at most SRK_WS_NF frames: the MFMA kernel
-        if (env_valu) hipLaunchKernelGGL(k_schur_ws<double>, grid, block, 0, s, SRK_SCHUR_ARGS);
-        else hipLaunchKernelGGL(k_schur_mm, grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS);
+        if (env_valu) SRK_SCHUR_LAUNCH(k_schur_ws, block, double, );
+        else SRK_SCHUR_LAUNCH(k_schur_mm, dim3(SRK_MM_THREADS), );
     }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread
-        if (fp32_accumulate) hipLaunchKernelGGL((k_schur_grouped<1, float>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
-        else hipLaunchKernelGGL((k_schur_grouped<1, double>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
+        if (fp32_accumulate) SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 1, float, );
+        else SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 1, double, );
     }
     if (n_wide > 0) { // more than SRK_GRP_NF1 frames: two half blocks per thread
-        if (fp32_accumulate) hipLaunchKernelGGL((k_schur_grouped<2, float>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
-        else hipLaunchKernelGGL((k_schur_grouped<2, double>), grid, block, 0, s, SRK_SCHUR_ARGS, nf_skip);
+        if (fp32_accumulate) SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 2, float, );
+        else SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 2, double, );
     }
+#undef SRK_SCHUR_LAUNCH
+#undef SRK_SCHUR_LAUNCH_SKIP
 #undef SRK_SCHUR_ARGS
 }
 
@@ -1791,8 +1827,9 @@ void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S)
 
 // ------------------------------------------------------------------ K5: back-substitution + landmark update
 // thread per observation: t = W_ij dc_j (3-vector), segmented wave reduction by landmark, one atomic per segment
+template <typename WT>
 __global__ __launch_bounds__(256) void k_backsub_obs(SrkDims d, const int32_t* __restrict__ obs_frame,
-                                                     const int32_t* __restrict__ obs_pt, const double* __restrict__ W,
+                                                     const int32_t* __restrict__ obs_pt, const WT* __restrict__ W,
                                                      const double* __restrict__ dc, double* __restrict__ acc)
 {
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1861,7 +1898,11 @@ void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t
     // the int right behind acc
     if (d.O > 0) {
         int64_t blocks = (d.O + 255) / 256;
-        hipLaunchKernelGGL(k_backsub_obs, dim3((unsigned)blocks), dim3(256), 0, s, d, obs_frame, obs_pt, W, dc, acc);
+        if (d.w_f32)
+            hipLaunchKernelGGL(k_backsub_obs<float>, dim3((unsigned)blocks), dim3(256), 0, s, d, obs_frame, obs_pt,
+                               reinterpret_cast<const float*>(W), dc, acc);
+        else
+            hipLaunchKernelGGL(k_backsub_obs<double>, dim3((unsigned)blocks), dim3(256), 0, s, d, obs_frame, obs_pt, W, dc, acc);
     }
     if (d.N > 0) {
         int* info = reinterpret_cast<int*>(acc + 3 * d.Ns);
