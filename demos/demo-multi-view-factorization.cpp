@@ -13,6 +13,7 @@
 // Harness additions: --max_frames, --ba_max_iterations (the reference has no cap), --dump_ba_prefix=<path> (the scene of
 // every BA call before / after, for the oracle comparison in tests/).  The last stdout line is a JSON summary.
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -180,7 +181,8 @@ int main(int argc, char** argv)
     BundleAdjustmentKanatani ba;
     const double kF0 = 1;
     long ba_calls = 0, ba_iterations = 0, ba_attempts = 0, integrated = 0, failed = 0;
-    double last_err = -1, max_pose_diff = 0;
+    double last_err = -1, max_pose_diff = 0, ba_ms_total = 0, ba_ms_max = 0;
+    size_t ba_last_points = 0, ba_last_frames = 0, ba_last_seen = 0;
 
     auto image_coord = [&](const Point2f& pix) { return matvec(Kinv, V3{ pix.x, pix.y, 1 }); };
     auto detect_and_match = [&](size_t f, bool create_points) { // DemoCornersMatcher (:302-348) / the demo's own loop (:548-600)
@@ -288,7 +290,14 @@ int main(int argc, char** argv)
             BundleAdjustmentKanataniTermCriteria crit;
             crit.AllowedReprojErrRelativeChange(1e-3);
             if (!dump_prefix.empty()) DumpScene(dump_prefix + "_" + std::to_string(ba_calls) + "_before.bin", kF0, map, cams, tracks, &K, nullptr);
+            const auto t_ba = std::chrono::steady_clock::now();
             op = ba.ComputeInplace(kF0, map, cams, tracks, &K, nullptr, crit, ba_max_iterations);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ba).count();
+            ba_ms_total += ms;
+            if (ms > ba_ms_max) ba_ms_max = ms;
+            ba_last_points = ba.PointsCount();
+            ba_last_frames = ba.FramesCount();
+            ba_last_seen = (size_t)ba.Report().seen;
             if (!dump_prefix.empty()) DumpScene(dump_prefix + "_" + std::to_string(ba_calls) + "_after.bin", kF0, map, cams, tracks, &K, nullptr);
             std::fprintf(stderr, "bundle adjustment finished with result: %d (%s)\n", (int)op, ba.OptimizationStatusString().c_str());
             ++ba_calls;
@@ -303,8 +312,10 @@ int main(int argc, char** argv)
     for (const CornerTrack& t : tracks.CornerTracks) reconstructed_points += t.SalientPointId ? 1 : 0;
     std::printf("{\"frames\": %zu, \"world_points\": %zu, \"tracks\": %zu, \"salient_points\": %zu, \"integrated_frames\": %ld, "
                 "\"failed_frames\": %ld, \"ba_calls\": %ld, \"ba_iterations\": %ld, \"ba_attempts\": %ld, \"last_reproj_err\": %.17g, "
-                "\"max_pose_diff\": %.6g}\n",
+                "\"max_pose_diff\": %.6g, \"ba_ms_total\": %.3f, \"ba_ms_max\": %.3f, \"ba_last_points\": %zu, "
+                "\"ba_last_frames\": %zu, \"ba_last_observations\": %zu}\n",
                 cams.size(), world.size(), tracks.CornerTracks.size(), reconstructed_points, integrated, failed, ba_calls,
-                ba_iterations, ba_attempts, last_err, max_pose_diff);
+                ba_iterations, ba_attempts, last_err, max_pose_diff, ba_ms_total, ba_ms_max, ba_last_points, ba_last_frames,
+                ba_last_seen);
     return 0;
 }
