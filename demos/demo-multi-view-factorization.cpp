@@ -222,7 +222,10 @@ int main(int argc, char** argv)
                 if (tracks.CornerTracks[id].GetCorner(p) && tracks.CornerTracks[id].SalientPointId) ++cnt;
             if (cnt > best) { best = cnt; anchor = p; }
         }
-        if (best == 0) { std::fprintf(stderr, "Can't integrate frameInd=%zu\n", f); ++failed; continue; }
+        // The reference gives up here as well: IntegrateNewFrameCorners returns false before it adds a pose, its next call
+        // re-detects the same frame index (FramesCount()) and fails again (:262-270, "TODO: how to roll back").  The
+        // drop-in stops integrating instead of repeating the failure for every remaining frame.
+        if (best == 0) { std::fprintf(stderr, "Can't integrate frameInd=%zu\n", f); failed = (long)(frames_count - f); break; }
         std::vector<double> xa, xt, depth;
         for (size_t id : in_frame) {
             const CornerTrack& t = tracks.CornerTracks[id];
@@ -236,7 +239,13 @@ int main(int argc, char** argv)
         SE3Transform new_from_anchor;
         double Tn[3];
         const int mo = srk_mvf_relative_motion(ba.Handle(), (int64_t)depth.size(), xa.data(), xt.data(), depth.data(), new_from_anchor.R.data(), Tn);
-        if (mo != 1) { std::fprintf(stderr, "relative motion failed at frame %zu (%d)\n", f, mo); ++failed; continue; }
+        // fewer than 6 common points leave the 12-unknown system rank deficient (the reference takes whatever vector its
+        // SVD returns and carries on with a meaningless pose); srk_mvf_relative_motion refuses, and tracking ends here
+        if (mo != 1) {
+            std::fprintf(stderr, "tracking lost at frame %zu: relative motion from %zu common points failed (%d)\n", f, depth.size(), mo);
+            failed = (long)(frames_count - f);
+            break;
+        }
         new_from_anchor.T = { Tn[0], Tn[1], Tn[2] };
         { // distance from the ground-truth motion, as the reference logs it (:283-295)
             const SE3Transform gtm = se3_compose(gt[f], se3_inv(gt[anchor]));
