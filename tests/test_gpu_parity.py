@@ -585,6 +585,50 @@ def test_c2_full_size_blocks_system_and_one_iteration_vs_oracle(orc, gpu):
     assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
 
 
+def test_c3_full_size_blocks_and_reduced_system_vs_oracle(orc, gpu):
+    """BASELINE config 3 (the bench workload: 1000 cams / 100k pts / 2M obs) against the oracle for everything but the
+    dense solve (the oracle's Householder QR of the 9993^2 system would take hours): reprojection error, gradient,
+    point / frame / point-frame blocks (rel 1e-12, gradient 1e-10), and the whole reduced camera system and right-hand
+    side (rel 1e-10) -- 800 MB each side; the solve itself is covered at this size by
+    test_c3_solver_modes_agree_at_bench_size (three factorisations of the same system agree)."""
+    spec = sa.CONFIGS["C3_1kcam_100kpt"]
+    sc = sa.config_scene("C3_1kcam_100kpt")
+    so = _orc_scene(orc, sc)
+    ok, _ = orc.normalize(so)
+    assert ok and gpu.upload(spec.f0, sc)
+    eo, seen_o = orc.reproj_error(spec.f0, so)
+    eg, seen_g = gpu.phase_error()
+    assert seen_g == seen_o == 2000000 and eg == pytest.approx(eo, rel=1e-12)
+    gradE, V, U, W = orc.derivatives(spec.f0, so)
+    gpu.phase_derivatives()
+    assert rel_err(gpu.buffer(B.BUF_POINT_BLOCKS).reshape(-1, 3, 3), V) < 1e-12
+    assert rel_err(gpu.buffer(B.BUF_FRAME_BLOCKS).reshape(-1, 10, 10), U) < 1e-12
+    assert rel_err(gpu.buffer(B.BUF_GRAD), gradE) < 1e-10
+    Wg = gpu.buffer(B.BUF_POINT_FRAME).reshape(-1, 3, 10)
+    assert rel_err(Wg, W) < 1e-12
+    del Wg
+    orc.set_skip_solve(True)   # the system is formed, the QR is not run
+    try:
+        _, _, S, rhs = orc.two_phase(so, gradE, V, U, W, 1e-4, want_system=True)
+    finally:
+        orc.set_skip_solve(False)
+    del W
+    gpu.phase_schur(1e-4)
+    M = sc.M
+    keep = _reduced_index(M) >= 0
+    rg = gpu.buffer(B.BUF_RCS_RHS)
+    assert rel_err(rg[keep], rhs) < 1e-10
+    Sg = gpu.buffer(B.BUF_RCS).reshape(10 * M, 10 * M)
+    idx = np.where(keep)[0]
+    scale = float(np.abs(S).max())
+    worst = 0.0
+    for r0 in range(0, len(idx), 1000):          # row blocks: no second 800 MB copy
+        rows = idx[r0:r0 + 1000]
+        worst = max(worst, float(np.abs(Sg[np.ix_(rows, idx)] - S[r0:r0 + 1000]).max()))
+    assert worst < 1e-10 * scale
+    gpu.upload(SCENES["tiny"].f0, sa.generate_scene(SCENES["tiny"]))  # release the large buffers
+
+
 # ------------------------------------------------------------------ full-size properties (no oracle at this size)
 
 def test_c2_size_properties(gpu):
