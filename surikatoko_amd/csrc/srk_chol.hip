@@ -715,7 +715,8 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
 // j in [col_begin, 256 K).  Every product is "one column per lane, the rows split over the four waves, partial sums
 // combined through LDS": short independent load chains instead of 64- and 256-long ones.
 #define BWD_COLS 64
-__global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholStep Kst, const CholStep cbeg)
+// finite: the reference's allFinite check of the solution (:1912-1913) where this level's x IS the final solution (NULL below)
+__global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholStep Kst, const CholStep cbeg, int* __restrict__ finite)
 {
     __shared__ double sv[NBO];
     __shared__ double sp[4][NBO - NB];
@@ -769,7 +770,10 @@ __global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholSte
         if (t < sub * NB) sv[t] -= (sp[0][t] + sp[1][t]) + (sp[2][t] + sp[3][t]);
         __syncthreads();
     }
-    if (blockIdx.x == 0) x[k0 + t] = sv[t];
+    if (blockIdx.x == 0) {
+        x[k0 + t] = sv[t];
+        if (finite && !isfinite(sv[t])) atomicOr(finite, 4);
+    }
     const int64_t j = col_begin + (int64_t)blockIdx.x * BWD_COLS + lane;
     double acc = 0;
     if (j < k0) {
@@ -780,13 +784,6 @@ __global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholSte
     sp[wv][lane] = acc;
     __syncthreads();
     if (wv == 0 && j < k0) y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
-}
-
-// the solution must be all finite (the reference's allFinite check, :1912-1913)
-__global__ __launch_bounds__(256) void k_check_finite(int64_t n, const double* __restrict__ x, int* __restrict__ info)
-{
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n && !isfinite(x[i])) atomicOr(info, 4);
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -868,7 +865,7 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
 
 // chol_bwd: x = L^-T y over the first `ncols` columns of every item (the border part, if any, has been folded into y
 // already).  Launch t serves outer panel nout_i - 1 - t of item i.
-static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, SrkSolveProf* prof)
+static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, SrkSolveProf* prof, int* d_finite)
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
@@ -889,7 +886,7 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
             Kst.v[i] = K;
             cbeg.v[i] = cb;
         }
-        LAUNCH(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg);
+        LAUNCH(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg, d_finite);
     }
 }
 
@@ -906,8 +903,7 @@ void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, 
     H.row_end = row_end;
     H.col_begin = col_begin;
     chol_factor(s, B, 1, &H, d_info, prof);
-    chol_bwd(s, B, 1, &H, prof);
-    LAUNCH(k_check_finite, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ld, x, d_info);
+    chol_bwd(s, B, 1, &H, prof, d_info); // every variable is written by a k_bwd256 step, which checks it
 }
 
 // ================================================================ chunked (bordered block-diagonal) solve
@@ -979,8 +975,9 @@ __global__ __launch_bounds__(256) void k_level_gather(const double* __restrict__
             int64_t c0 = env_col[g / 128] - a;
             if (c0 < 0) c0 = 0;
             const int64_t c1 = 128 * (i / 128 + 1); // end of this row's skyline segment (tile aligned, <= nc)
-            const double* src = S + g * ld + a;
-            for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) dst[j] = src[j];
+            const double2* src = reinterpret_cast<const double2*>(S + g * ld + a); // c0, c1: multiples of 128
+            double2* d2 = reinterpret_cast<double2*>(dst);
+            for (int64_t j = c0 / 2 + threadIdx.x; j < c1 / 2; j += 256) d2[j] = src[j];
             if (threadIdx.x == 0) wc[i] = rhs[g];
             continue;
         }
@@ -991,13 +988,16 @@ __global__ __launch_bounds__(256) void k_level_gather(const double* __restrict__
         if (u2 < sepw) {
             // the coupling with the separator above lives in S[a + j][a - sepw + u2], j < sepw (the separator is at least
             // one bandwidth wide): a TRANSPOSED block, copied by the tile workgroups; this row only clears the rest
-            const int64_t jn = has_top ? (nc < sepw ? nc : sepw) : 0;
-            for (int64_t j = jn + threadIdx.x; j < jend; j += 256) dst[j] = 0.0;
+            const int64_t jn = has_top ? (nc < sepw ? nc : sepw) : 0; // jn, jend, ldc: multiples of 64 -> 16-byte stores
+            double2* d2 = reinterpret_cast<double2*>(dst);
+            for (int64_t j = jn / 2 + threadIdx.x; j < jend / 2; j += 256) d2[j] = make_double2(0.0, 0.0);
         } else {
             const int64_t g = a + nc + (u2 - sepw);
             const int64_t j0 = nc > 2 * sepw ? nc - 2 * sepw : 0;
-            for (int64_t j = threadIdx.x; j < jend; j += 256)
-                dst[j] = (has_bot && j >= j0 && j < nc) ? S[g * ld + a + j] : 0.0;
+            const double2* s2 = reinterpret_cast<const double2*>(S + g * ld + a); // a, j0, nc: even
+            double2* d2 = reinterpret_cast<double2*>(dst);
+            for (int64_t j = threadIdx.x; j < jend / 2; j += 256)
+                d2[j] = (has_bot && 2 * j >= j0 && 2 * j < nc) ? s2[j] : make_double2(0.0, 0.0);
         }
         if (threadIdx.x == 0) wc[i] = 0.0;
     }
@@ -1025,7 +1025,12 @@ __global__ __launch_bounds__(256) void k_sep_reduce(const CholBatch B, int64_t s
 
 // border part of a chunk's solution = the separator solution; fold it into y: y_j -= sum_i L[nc + i][j] x[nc + i].
 // A workgroup takes 64 columns; its four waves split the 2 sepw border rows and combine through LDS.
-__global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs)
+// The first column workgroup of chunk c also places the solution of the separator below it into the level's solution
+// vector x (and checks it where x is the final solution): with the chunk interiors written there directly by k_bwd256
+// (their CholItem::x points into x), no scatter launch is left.
+__global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs,
+                                                    const int64_t* __restrict__ sep_start, double* __restrict__ x,
+                                                    int* __restrict__ finite)
 {
     __shared__ double sx[2 * SRK_MAX_SEPW];
     __shared__ double sp[4][64];
@@ -1033,6 +1038,12 @@ __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, in
     const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;
     if ((int64_t)blockIdx.x * 64 >= nc) return;
     const int64_t top_sep = c > 0 ? c - 1 : -1, bot_sep = c < P - 1 ? c : -1;
+    if (blockIdx.x == 0 && bot_sep >= 0)
+        for (int64_t u = threadIdx.x; u < sepw; u += 256) {
+            const double v = xs[bot_sep * sepw + u];
+            x[sep_start[bot_sep] + u] = v;
+            if (finite && !isfinite(v)) atomicOr(finite, 4);
+        }
     for (int64_t u2 = threadIdx.x; u2 < 2 * sepw; u2 += 256) {
         const int64_t su = u2 < sepw ? top_sep : bot_sep;
         sx[u2] = su < 0 ? 0.0 : xs[su * sepw + (u2 < sepw ? u2 : u2 - sepw)];
@@ -1050,22 +1061,6 @@ __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, in
     if (wave == 0) B.it[c].y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
-// the level's solution: chunk interiors (blockIdx.z < P) and separator variables (blockIdx.z == P)
-// (finite: the top level's scatter also is the reference's allFinite check of the solution, :1912-1913; NULL below it)
-__global__ __launch_bounds__(256) void k_level_scatter(const CholBatch B, const CholStep first, int P, int64_t sepw,
-                                                       const int64_t* __restrict__ sep_start, const double* __restrict__ xs,
-                                                       int64_t lds, double* __restrict__ x, int* __restrict__ finite)
-{
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double v = 0.0;
-    if ((int)blockIdx.z == P) {
-        if (j < lds) x[sep_start[j / sepw] + j % sepw] = v = xs[j];
-    } else if (j < B.it[blockIdx.z].ncols) {
-        x[first.v[blockIdx.z] + j] = v = B.it[blockIdx.z].x[j];
-    }
-    if (finite && !isfinite(v)) atomicOr(finite, 4);
-}
-
 static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs, double* x,
                           const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, bool top)
 {
@@ -1079,7 +1074,8 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
     int64_t max_ldc = 0, max_nc = 0;
     for (int c = 0; c < SRK_MAX_CHUNKS; ++c) first.v[c] = 0;
     for (int c = 0; c < P; ++c) {
-        B.it[c] = CholItem{ pl.Ac[c], pl.wc[c], pl.yc[c], pl.xc[c], pl.dinvc[c], pl.ldc[c], pl.n[c], pl.n[c], pl.ldc[c] };
+        // a chunk's solution goes straight to its place in the level's solution vector
+        B.it[c] = CholItem{ pl.Ac[c], pl.wc[c], pl.yc[c], x + pl.a[c], pl.dinvc[c], pl.ldc[c], pl.n[c], pl.n[c], pl.ldc[c] };
         H[c].row_end = pl.row_end[c].data();
         H[c].col_begin = pl.col_begin[c].data();
         H[c].r2_split = pl.n[c] + sepw;
@@ -1102,17 +1098,17 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
         solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof, false);
     } else {
         chol_factor(s, Bs, 1, &Hs, d_info, prof);
-        chol_bwd(s, Bs, 1, &Hs, prof);
+        chol_bwd(s, Bs, 1, &Hs, prof, nullptr);
     }
-    LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs);
-    chol_bwd(s, B, P, H, prof);
-    LAUNCH(k_level_scatter, dim3((unsigned)((std::max(max_nc, lds) + 255) / 256), 1, (unsigned)(P + 1)), dim3(256), 0, s, B,
-           first, P, sepw, pl.d_sep_start, pl.xs, lds, x, top ? d_info : nullptr);
+    int* d_finite = top ? d_info : nullptr;
+    LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs, pl.d_sep_start, x,
+           d_finite);
+    chol_bwd(s, B, P, H, prof, d_finite);
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
                             double* x, const int64_t* d_env_col, int* d_info, SrkSolveProf* prof)
 {
-    // every variable of the system is a chunk or a separator variable of the top level: its scatter checks them all
+    // every variable of the system is a chunk or a separator variable of the top level: its backward kernels check them all
     solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true);
 }
