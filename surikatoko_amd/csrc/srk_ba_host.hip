@@ -55,6 +55,9 @@ struct srk_ba {
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
     DevBuf grp_first, grp_count, grp_nf, grp_frames, obs_slot, pt_mask, gen_list, wg_jmin;
+    // long tracks (more than SRK_GRP_MAXNF_HOST frames): runs over frame-block pairs, k_schur_long
+    DevBuf lg_item, lg_np, lg_nf, lg_pts, lg_frames, lg_obs_off, lg_obs;
+    int64_t n_long_items = 0, n_long_runs = 0;
     DevBuf sc_pts, sc_R, sc_T, sc_K, sc_cam, sc_frame, sc_pt, sc_uv, sc_partial, sc_out; // standalone scoring path
     int64_t n_groups = 0, n_groups_wide = 0, n_groups_mid = 0, n_generic = 0;
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
@@ -253,7 +256,8 @@ void srk_ba_destroy(srk_ba* h)
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
                       &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off,
-                      &h->jr_first, &h->jr_count, &h->jr_jmin };
+                      &h->jr_first, &h->jr_count, &h->jr_jmin, &h->lg_item, &h->lg_np, &h->lg_nf, &h->lg_pts, &h->lg_frames,
+                      &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
         for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed }) dev_free(*b);
@@ -720,7 +724,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     // not see one of them contributes zeros there.  Identical lists (the circle-grid scenes) are the special case
     // union == list ("uniform" run: no slot table needed); ragged feature tracks, where hardly two landmarks see
     // exactly the same frames, still share a window of frames.  Landmarks with more frames -> per-landmark kernel.
-    std::vector<int32_t> grp_first, grp_count, grp_nf, grp_frames, gen_list;
+    std::vector<int32_t> grp_first, grp_count, grp_nf, grp_frames, gen_list, long_cand;
     std::vector<uint8_t> obs_slot((size_t)O, 0);
     std::vector<uint32_t> pt_mask((size_t)N, 0);
     int64_t n_wide = 0, n_mid = 0;
@@ -729,7 +733,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         for (int64_t i = 0; i < N;) {
             const int64_t nfi = rp[(size_t)i + 1] - rp[(size_t)i];
             if (nfi == 0) { ++i; continue; }
-            if (nfi > SRK_GRP_MAXNF_HOST) { gen_list.push_back((int32_t)i); ++i; continue; }
+            if (nfi > SRK_GRP_MAXNF_HOST) { long_cand.push_back((int32_t)i); ++i; continue; }
             const int64_t cap = nfi > SRK_GRP_NF1_HOST ? SRK_GRP_MAXNF_HOST : SRK_GRP_NF1_HOST;
             uni.assign(of.begin() + rp[(size_t)i], of.begin() + rp[(size_t)i + 1]);
             int64_t j = i + 1;
@@ -766,6 +770,60 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             i = j;
         }
     }
+    // Long tracks (> SRK_GRP_MAXNF_HOST frames; every track of the demos' all-visible scenes): runs of consecutive
+    // candidates over the union of their frame lists (<= SRK_LONG_MAXNF_HOST frames), cut into blocks of 8 frames; one
+    // work item per pair of blocks (k_schur_long).  A track over more frames than a run holds keeps the per-landmark kernel.
+    std::vector<int32_t> lg_item, lg_np, lg_nf, lg_pts, lg_frames, lg_obs;
+    std::vector<int64_t> lg_obs_off;
+    if (getenv("SRK_SCHUR_NO_LONG")) { // development: everything through the per-landmark kernel
+        gen_list.insert(gen_list.end(), long_cand.begin(), long_cand.end());
+        long_cand.clear();
+    }
+    {
+        std::vector<int32_t> uni, merged;
+        for (size_t ci = 0; ci < long_cand.size();) {
+            const int64_t i = long_cand[ci];
+            const int64_t nfi = rp[(size_t)i + 1] - rp[(size_t)i];
+            if (nfi > SRK_LONG_MAXNF_HOST) { gen_list.push_back((int32_t)i); ++ci; continue; }
+            uni.assign(of.begin() + rp[(size_t)i], of.begin() + rp[(size_t)i + 1]);
+            size_t cj = ci + 1;
+            while (cj < long_cand.size() && cj - ci < SRK_LONG_PTS_HOST) {
+                const int64_t j = long_cand[cj];
+                if (rp[(size_t)j + 1] - rp[(size_t)j] > SRK_LONG_MAXNF_HOST) break;
+                merged.clear();
+                std::set_union(uni.begin(), uni.end(), of.begin() + rp[(size_t)j], of.begin() + rp[(size_t)j + 1],
+                               std::back_inserter(merged));
+                if ((int64_t)merged.size() > SRK_LONG_MAXNF_HOST) break;
+                // every landmark of the run pays for the whole union: let it grow freely only while the run is small
+                if (merged.size() > uni.size() && cj - ci >= 16 && (int64_t)merged.size() > nfi + nfi / 4 + SRK_LONG_FB_HOST) break;
+                uni.swap(merged);
+                ++cj;
+            }
+            const int32_t run = (int32_t)lg_np.size();
+            const int nfu = (int)uni.size(), nb = (nfu + SRK_LONG_FB_HOST - 1) / SRK_LONG_FB_HOST, nfp = nb * SRK_LONG_FB_HOST;
+            lg_np.push_back((int32_t)(cj - ci));
+            lg_nf.push_back((int32_t)nfu);
+            for (int k = 0; k < SRK_LONG_PTS_HOST; ++k) lg_pts.push_back(ci + k < cj ? long_cand[ci + (size_t)k] : 0);
+            for (int k = 0; k < SRK_LONG_MAXNF_HOST; ++k) lg_frames.push_back(k < nfu ? uni[(size_t)k] : -1);
+            lg_obs_off.push_back((int64_t)lg_obs.size());
+            for (size_t ck = ci; ck < cj; ++ck) {
+                const int64_t p = long_cand[ck];
+                const size_t base = lg_obs.size();
+                lg_obs.resize(base + (size_t)nfp, -1);
+                for (int64_t o = rp[(size_t)p]; o < rp[(size_t)p + 1]; ++o) {
+                    const int slot = (int)(std::lower_bound(uni.begin(), uni.end(), of[(size_t)o]) - uni.begin());
+                    lg_obs[base + (size_t)slot] = (int32_t)o;
+                }
+            }
+            for (int a = 0; a < nb; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    lg_item.push_back(run); lg_item.push_back(a); lg_item.push_back(b); lg_item.push_back(0);
+                }
+            ci = cj;
+        }
+    }
+    h->n_long_runs = (int64_t)lg_np.size();
+    h->n_long_items = (int64_t)lg_item.size() / 4;
     h->n_groups = (int64_t)grp_first.size();
     h->n_groups_wide = n_wide;
     h->n_groups_mid = n_mid;
@@ -926,6 +984,13 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->obs_slot, obs_slot.size());
     ALLOC(h->pt_mask, 4 * pt_mask.size());
     ALLOC(h->gen_list, 4 * gen_list.size());
+    ALLOC(h->lg_item, 4 * lg_item.size());
+    ALLOC(h->lg_np, 4 * lg_np.size());
+    ALLOC(h->lg_nf, 4 * lg_nf.size());
+    ALLOC(h->lg_pts, 4 * lg_pts.size());
+    ALLOC(h->lg_frames, 4 * lg_frames.size());
+    ALLOC(h->lg_obs_off, 8 * lg_obs_off.size());
+    ALLOC(h->lg_obs, 4 * lg_obs.size());
     ALLOC(h->wg_jmin, 4 * wg_jmin.size());
     if (h->jac_runs) {
         ALLOC(h->jr_first, 4 * jr_first.size());
@@ -959,6 +1024,13 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->obs_slot, obs_slot.data(), obs_slot.size());
     H2D(h->pt_mask, pt_mask.data(), 4 * pt_mask.size());
     H2D(h->gen_list, gen_list.data(), 4 * gen_list.size());
+    H2D(h->lg_item, lg_item.data(), 4 * lg_item.size());
+    H2D(h->lg_np, lg_np.data(), 4 * lg_np.size());
+    H2D(h->lg_nf, lg_nf.data(), 4 * lg_nf.size());
+    H2D(h->lg_pts, lg_pts.data(), 4 * lg_pts.size());
+    H2D(h->lg_frames, lg_frames.data(), 4 * lg_frames.size());
+    H2D(h->lg_obs_off, lg_obs_off.data(), 8 * lg_obs_off.size());
+    H2D(h->lg_obs, lg_obs.data(), 4 * lg_obs.size());
     H2D(h->wg_jmin, wg_jmin.data(), 4 * wg_jmin.size());
     if (h->jac_runs) {
         H2D(h->jr_first, jr_first.data(), 4 * jr_first.size());
@@ -1138,6 +1210,9 @@ static int phase_schur(srk_ba* h, double c)
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S),
                              P<double>(h->A->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
                              P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0);
+    srk_launch_schur_long(s, d, c, P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S), P<double>(h->A->rhs),
+                          P<int32_t>(h->lg_item), h->n_long_items, P<int32_t>(h->lg_np), P<int32_t>(h->lg_nf), P<int32_t>(h->lg_pts),
+                          P<int32_t>(h->lg_frames), P<int64_t>(h->lg_obs_off), P<int32_t>(h->lg_obs));
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->A->S), P<double>(h->A->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());

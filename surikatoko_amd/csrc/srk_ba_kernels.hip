@@ -1723,6 +1723,174 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #endif
 }
 
+// ------------------------------------------------------------------ K3l: long tracks as frame-block pairs (fp64 MFMA)
+// Landmarks seen by more than SRK_GRP_MAXNF frames (the demos' all-visible scenes: 36 and 60 frames; the MVF driver
+// calls the path with every track in every frame) used to go through the per-landmark kernel k_schur: one workgroup
+// per landmark, nf (nf + 1) / 2 blocks of global fp64 atomics each -- 9 ms an attempt on the 60-frame / 3321-point MVF
+// flagfile scene.  The run sum as a matrix product (k_schur_mm) generalises when the frame set of a run is cut into
+// blocks of SRK_LONG_FB = 8 frames (80 columns = five 16-column MFMA tiles exactly): a workgroup takes ONE pair
+// (bi >= bj) of frame blocks of a run of <= SRK_LONG_PTS landmarks,
+//     sum_i W_i[:, bi]^T E_i^-1 W_i[:, bj]   =   Wl[:, bi]^T Yl[:, bj],     an 80 x 80 x (3 np) product,
+// with rows k = (landmark, point coordinate) as in k_schur_mm.  Five waves, wave w owns tile row w of the 5 x 5 tile
+// grid (one A operand read serves five MFMAs); every lane also stages: rounds of eight landmarks (24 k rows = six
+// K = 4 steps), lane (side, landmark, frame, half block) loads 15 entries of its observation's W block -- all three
+// point coordinates, so it forms its part of Y = E^-1 W in registers -- with the next round's loads in flight during
+// this round's MFMAs; two LDS buffers, one LDS-only barrier a round.  The run's frame set is a union (a landmark that
+// misses a frame contributes zeros there); the table `run_obs` (host) maps (landmark, frame slot) to the observation.
+// Pairs on the diagonal compute all 25 tiles and flush the lower block triangle; they also carry the block's part of
+// the right-hand side.  The sums leave as fp64 atomics, once per pair and run.
+#define SRK_LONG_FB 8
+#define SRK_LONG_RB 8     // landmarks per round
+#define SRK_LONG_LD 80    // LDS row stride in doubles (= 16 mod 32: the four k rows of an operand hit different banks)
+#define SRK_LONG_THREADS 320
+static_assert(SRK_LONG_FB * 10 == SRK_LONG_LD && SRK_LONG_LD % 16 == 0, "a frame block is a whole number of MFMA tiles");
+static_assert(SRK_LONG_THREADS / 64 * 16 == SRK_LONG_LD, "one wave per tile row");
+static_assert(2 * SRK_LONG_RB * SRK_LONG_FB * 2 <= SRK_LONG_THREADS && SRK_LONG_PTS_HOST <= SRK_LONG_THREADS, "staging lanes");
+template <typename WT>
+__global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
+    SrkDims d, double c, const WT* __restrict__ W, const double* __restrict__ Vg, double* __restrict__ S,
+    double* __restrict__ rhs, const int32_t* __restrict__ item /* [n][4]: run, bi, bj, - */,
+    const int32_t* __restrict__ run_np, const int32_t* __restrict__ run_nf,
+    const int32_t* __restrict__ run_pts /* [run][SRK_LONG_PTS] */, const int32_t* __restrict__ run_frames /* [run][SRK_LONG_MAXNF] */,
+    const int64_t* __restrict__ run_obs_off, const int32_t* __restrict__ run_obs /* [off + landmark * nfp + slot] or -1 */)
+{
+    constexpr int LD = SRK_LONG_LD, RB = SRK_LONG_RB, KR = 3 * RB, BUF = KR * LD;
+    __shared__ __attribute__((aligned(16))) double sW[2][BUF];
+    __shared__ __attribute__((aligned(16))) double sY[2][BUF];
+    __shared__ __attribute__((aligned(16))) double sE[SRK_LONG_PTS_HOST][12];
+    __shared__ double sRhs[LD];
+    __shared__ int32_t sVar[2][LD]; // row / column of S of the pair's row / column e; -1: gauge-fixed or beyond the run's frames
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int run = item[4 * blockIdx.x], bi = item[4 * blockIdx.x + 1], bj = item[4 * blockIdx.x + 2];
+    const int np = run_np[run], nf = run_nf[run];
+    const int nfp = SRK_LONG_FB * ((nf + SRK_LONG_FB - 1) / SRK_LONG_FB);
+    const bool diag = bi == bj;
+    const int32_t* pts = run_pts + (int64_t)run * SRK_LONG_PTS_HOST;
+    const int32_t* obs = run_obs + run_obs_off[run];
+    if (tid < 2 * LD) {
+        const int side = tid / LD, e = tid - side * LD;
+        const int slot = SRK_LONG_FB * (side ? bj : bi) + e / 10;
+        int var = -1;
+        if (slot < nf) {
+            const int64_t v = 10 * (int64_t)run_frames[(int64_t)run * SRK_LONG_MAXNF_HOST + slot] + e % 10;
+            var = srk_is_fixed_var(v, d.comp) ? -1 : (int)v;
+        }
+        sVar[side][e] = var;
+    }
+    if (tid < LD) sRhs[tid] = 0.0;
+    if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
+        double Einv[9], g[3];
+        const bool ok = point_block_inverse(Vg, d.Ns, pts[tid], c, Einv, g);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
+    }
+    // staging lane: side 0 = block bi (-> W, and Y too on a diagonal pair), side 1 = block bj (-> Y)
+    const int side = tid >> 7, within = tid & 127;
+    const int spl = within >> 4, sa = (within >> 1) & 7, sh = within & 1;
+    const bool stager = tid < 256 && (side == 0 || !diag);
+    const int sslot = SRK_LONG_FB * (side ? bj : bi) + sa;
+    const int sdst = 3 * spl * LD + 10 * sa + 5 * sh;
+    double pre[15];
+    auto load_round = [&](int r) { // global loads of round r into `pre` (left in flight); zeros where nothing is observed
+        const int pl = r * RB + spl;
+        int64_t o = -1;
+        if (stager && pl < np) o = obs[(int64_t)pl * nfp + sslot];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) pre[i] = 0.0;
+        if (o >= 0) {
+            const WT* src = W + (int64_t)(5 * sh) * d.Os + o;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) pre[5 * m + i] = (double)src[(int64_t)(10 * m + i) * d.Os];
+        }
+    };
+    double racc[5] = { 0, 0, 0, 0, 0 };
+    auto stage_round = [&](int r, int b) { // `pre` -> W / Y of round r in buffer b
+        if (!stager) return;
+        const int pl = r * RB + spl < np ? r * RB + spl : 0; // (a landmark past the run's end staged zeros)
+        if (side == 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) sW[b][sdst + m * LD + i] = pre[5 * m + i];
+        }
+        if (side == 1 || diag) {
+            const double* E = sE[pl];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    sY[b][sdst + m * LD + i] = E[3 * m] * pre[i] + E[3 * m + 1] * pre[5 + i] + E[3 * m + 2] * pre[10 + i];
+        }
+        if (diag) { // rhs += F^T E^-1 g (:1895-1897), this block's columns
+#pragma unroll
+            for (int i = 0; i < 5; ++i) racc[i] += pre[i] * sE[pl][9] + pre[5 + i] * sE[pl][10] + pre[10 + i] * sE[pl][11];
+        }
+    };
+    const int R = (np + RB - 1) / RB;
+    load_round(0);
+    __syncthreads(); // sE, sVar, sRhs
+    const int lr = lane & 15, lk = lane >> 4;
+    srk_double4 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[t] = (srk_double4){ 0, 0, 0, 0 };
+    for (int r = 0; r < R; ++r) {
+        const int b = r & 1;
+        stage_round(r, b);
+        if (r + 1 < R) load_round(r + 1);
+        lds_barrier(); // round r is staged; every wave is done with round r - 1 (the buffer round r + 1 overwrites)
+        const double* bw = sW[b] + lk * LD + 16 * wv + lr;
+        const double* by = sY[b] + lk * LD + lr;
+#pragma unroll
+        for (int ks = 0; ks < KR / 4; ++ks) {
+            const double a = bw[4 * ks * LD];
+            double bb[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) bb[t] = by[4 * ks * LD + 16 * t];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb[t], acc[t], 0, 0, 0);
+        }
+    }
+    // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int col = 16 * t + lr, vc = sVar[1][col];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * wv + lk + 4 * reg, vr = sVar[0][row];
+            if (vr < 0 || vc < 0) continue;
+            if (diag && col / 10 > row / 10) continue; // lower block triangle (whole diagonal blocks, as the other kernels)
+            atomicAdd(&S[(int64_t)vr * d.ld + vc], -acc[t][reg]);
+        }
+    }
+    if (diag) {
+        if (stager) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) atomicAdd(&sRhs[10 * sa + 5 * sh + i], racc[i]);
+        }
+        __syncthreads();
+        if (tid < LD && sVar[0][tid] >= 0) atomicAdd(&rhs[sVar[0][tid]], sRhs[tid]);
+    }
+}
+
+void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const double* W, const double* Vg, double* S, double* rhs,
+                           const int32_t* item, int64_t n_items, const int32_t* run_np, const int32_t* run_nf,
+                           const int32_t* run_pts, const int32_t* run_frames, const int64_t* run_obs_off, const int32_t* run_obs)
+{
+    if (n_items <= 0) return;
+    if (d.w_f32)
+        hipLaunchKernelGGL(k_schur_long<float>, dim3((unsigned)n_items), dim3(SRK_LONG_THREADS), 0, s, d, c,
+                           reinterpret_cast<const float*>(W), Vg, S, rhs, item, run_np, run_nf, run_pts, run_frames, run_obs_off,
+                           run_obs);
+    else
+        hipLaunchKernelGGL(k_schur_long<double>, dim3((unsigned)n_items), dim3(SRK_LONG_THREADS), 0, s, d, c, W, Vg, S, rhs, item,
+                           run_np, run_nf, run_pts, run_frames, run_obs_off, run_obs);
+}
+
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,

@@ -73,6 +73,17 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */,
                               int64_t n_mid /* runs with SRK_WS_NF_HOST < frames <= SRK_GRP_NF1_HOST */,
                               int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */);
+// tracks longer than SRK_GRP_MAXNF_HOST frames: runs of <= SRK_LONG_PTS_HOST landmarks over a frame set of
+// <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur
+#define SRK_LONG_PTS_HOST 128
+#define SRK_LONG_MAXNF_HOST 128
+#define SRK_LONG_FB_HOST 8
+void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const double* W, const double* Vg, double* S, double* rhs,
+                           const int32_t* item /* [n_items][4]: run, row block, column block (<= row block), 0 */,
+                           int64_t n_items, const int32_t* run_np, const int32_t* run_nf,
+                           const int32_t* run_pts /* [run][SRK_LONG_PTS_HOST] landmarks (internal order) */,
+                           const int32_t* run_frames /* [run][SRK_LONG_MAXNF_HOST] the run's frame set, ascending */,
+                           const int64_t* run_obs_off, const int32_t* run_obs /* [off + landmark * 8 ceil(nf / 8) + slot]: observation or -1 */);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
                          double ident /* diagonal of fixed / padding variables */);
 void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,
