@@ -233,6 +233,14 @@ int srk_ba_rcs_chunks(srk_ba*); /* number of chunks of the current plan (0 = one
 double srk_ba_rcs_fill(srk_ba*); /* skyline size / lower-triangle size */
 double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates of one solve (current mode / plan) */
 
+/* Solver launch structure (harness knob; the reference has one dense solve, bundle-adj-kanatani.cpp:1911): 1 (default) =
+ * each 256-column outer step of the blocked Cholesky is ONE launch whose workgroups hand factored tiles to one another
+ * (bounded spins; a timed-out hand-off makes the LM loop repeat that attempt with the unfused sequence and stay there),
+ * 0 = one launch per 64-column panel and per rank-64 update.  Both give bit-identical results.  Takes effect at once.
+ * srk_ba_solver_sync_timeouts: how many solves had to be repeated (0 in every run so far). */
+int srk_ba_set_solver_fusion(srk_ba*, int on);
+int64_t srk_ba_solver_sync_timeouts(srk_ba*);
+
 /* Speculative attempts (default on; takes effect at the next upload): with the instrumentation off
  * (srk_ba_set_profile 0, the default) the LM loop runs the next damping factor on a second stream beside the current
  * one and judges the attempts in the reference's order, so results are those of the sequential loop; costs a second

@@ -281,6 +281,14 @@ class BundleAdjustmentKanatani:
         """Run the next damping factor beside the current attempt (one rank, instrumentation off); next upload."""
         self._raise(self._lib.srk_ba_set_speculation(C.c_void_p(self._h), C.c_int(int(bool(on)))))
 
+    def set_solver_fusion(self, on=True):
+        """Outer steps of the blocked Cholesky as one launch each (default) or as the panel / update launch sequence."""
+        self._raise(self._lib.srk_ba_set_solver_fusion(C.c_void_p(self._h), C.c_int(int(bool(on)))))
+
+    def solver_sync_timeouts(self):
+        self._lib.srk_ba_solver_sync_timeouts.restype = C.c_int64
+        return int(self._lib.srk_ba_solver_sync_timeouts(C.c_void_p(self._h)))
+
     def set_jacobian_mode(self, mode=-1):
         """-1 automatic, 0 = per-observation kernels only, 1 = run-based whenever possible (next upload)"""
         self._raise(self._lib.srk_ba_set_jacobian_mode(C.c_void_p(self._h), C.c_int(mode)))

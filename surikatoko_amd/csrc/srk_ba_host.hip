@@ -23,6 +23,7 @@
 #include <iterator>
 #include <memory>
 #include <vector>
+#include <functional>
 
 namespace {
 
@@ -78,8 +79,9 @@ struct srk_ba {
     // corrections, the trial scene, the status words, and the stream it runs on.  Two slots let the loop run the next
     // damping factor speculatively beside the current one (the solve is a latency chain that leaves the chip idle).
     struct Attempt {
-        DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv, packed;
+        DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv, packed, sync_flags;
         SrkChunkPlan plan;
+        SrkCholSync sync;            // in-launch hand-offs of the fused outer-step kernel (srk_chol.hip: k_step256)
         std::vector<DevBuf> plan_bufs;
         std::vector<char> plan_zeroed;   // plan_bufs[i] is a matrix / vector that must be zero outside what a solve writes
         std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
@@ -113,6 +115,8 @@ struct srk_ba {
     bool schur_fp32 = false; // opt-in mixed precision: fp32 run sums in the grouped Schur kernel
     bool store_f32 = false;  // opt-in: the point-frame blocks W are STORED as float (next upload); arithmetic stays fp64
     int profile_level = 0; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
+    bool chol_fused = true; // the solve's outer steps as one launch each (k_step256); srk_ba_set_solver_fusion
+    int64_t sync_timeouts = 0; // solves repeated with the unfused kernels after a hand-off timed out
     int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
     bool lean_resets = false; // srk_ba_optimize: no per-attempt memsets (see phase_solve)
@@ -221,6 +225,7 @@ srk_ba* srk_ba_create(int device_id)
         return nullptr;
     }
     h->main_stream = h->stream;
+    if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = e[0] != '0'; // development: the unfused launch sequence
     h->att[0].stream = h->stream;
     h->att[0].trial = 1;
     h->att[1].trial = 2;
@@ -260,7 +265,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
-        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed }) dev_free(*b);
+        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed, &a.sync_flags }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
@@ -976,6 +981,12 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         ALLOC(a.err_out, 64);
         ALLOC(a.info, 64);
         ALLOC(a.dinv, 8 * 64 * d.ld);
+        if (!a.sync_flags.p) { // flag words of the fused outer-step kernel: zeroed ONCE (they hold launch epochs)
+            ALLOC(a.sync_flags, 4 * SRK_SYNC_WORDS);
+            HIPCHK(h, hipMemset(a.sync_flags.p, 0, 4 * SRK_SYNC_WORDS));
+        }
+        a.sync.flags = P<unsigned>(a.sync_flags);
+        a.sync.fused = h->chol_fused;
     }
     ALLOC(h->grp_first, 4 * grp_first.size());
     ALLOC(h->grp_count, 4 * grp_count.size());
@@ -1242,10 +1253,10 @@ static void launch_solve(srk_ba* h, SrkSolveProf* prof)
     const SrkDims& d = h->d;
     if (h->A->plan.P >= 2)
         srk_chol_solve_chunked(h->stream, h->A->plan, d.ld, P<double>(h->A->S), P<double>(h->A->rhs), P<double>(h->A->dc),
-                               P<int64_t>(h->env_col), P<int>(h->A->info), prof);
+                               P<int64_t>(h->env_col), P<int>(h->A->info), prof, &h->A->sync);
     else
         srk_chol_solve(h->stream, d.ld, P<double>(h->A->S), P<double>(h->A->rhs), P<double>(h->A->wy), P<double>(h->A->dc),
-                       P<int>(h->A->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->A->dinv), prof);
+                       P<int>(h->A->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->A->dinv), prof, &h->A->sync);
 }
 
 static int phase_solve(srk_ba* h, bool profile)
@@ -1339,7 +1350,11 @@ int srk_ba_phase_solve(srk_ba* h)
     int info = 0;
     rc = read_info(h, &info);
     if (rc != SRK_OK) return rc;
-    if (info && srk_debug()) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution)\n", info);
+    if (info && srk_debug()) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution, 8 = hand-off timeout of the fused solve)\n", info);
+    if (info & 8) {
+        ++h->sync_timeouts;
+        h->last_error = "a hand-off of the fused solve timed out (srk_ba_set_solver_fusion(h, 0) selects the unfused launch sequence)";
+    }
     if (info) h->poisoned = true;
     return info ? 1 : 0;
 }
@@ -1499,9 +1514,18 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             return r2;
         };
         // wait for slot sl's attempt and judge it exactly as the reference judges the attempt with factor `hessian_factor`
+        std::function<int(int, double)> redo_unfused; // (defined below: repeats one attempt after a hand-off timeout)
         auto judge_attempt = [&](int sl) -> int {
             if (hipStreamSynchronize(h->att[sl].stream) != hipSuccess) return SRK_E_DEVICE;
             const double* hb = h->att[sl].host_back;
+            if (((int)hb[1] & 8) != 0) {
+                // an in-launch hand-off of the fused solve timed out (srk_chol.hip: k_step256; its spins are bounded): the
+                // numbers of this attempt are void.  From now on the unfused launch sequence (bit-identical arithmetic);
+                // this attempt is repeated with the factor it stands for, which is `hessian_factor` at this point.
+                int r2 = redo_unfused(sl, hessian_factor);
+                if (r2 != SRK_OK) return r2;
+                if (hipStreamSynchronize(h->att[sl].stream) != hipSuccess) return SRK_E_DEVICE;
+            }
             struct { double err; int info; } back{ hb[0], (int)hb[1] };
             const int info2 = (int)hb[2];
             rep->attempts += 1;
@@ -1530,6 +1554,17 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             err_new_prev = err_new;
             have_prev = true;
             return SRK_OK;
+        };
+        redo_unfused = [&](int sl, double c) -> int {
+            ++h->sync_timeouts;
+            if (srk_debug()) fprintf(stderr, "srk_ba[rank %d]: hand-off timeout in the fused solve (slot %d); repeating unfused\n", h->rank, sl);
+            h->chol_fused = false;
+            for (auto& a : h->att) a.sync.fused = false;
+            h->poisoned = true;
+            int r2 = clear_poison(h); // waits for both slots' streams, re-zeroes systems, plans, status words, accumulators
+            if (r2 == SRK_OK) r2 = enqueue_schur(sl, c);
+            if (r2 == SRK_OK) r2 = enqueue_rest(sl, c);
+            return r2;
         };
         // several ranks: one attempt at a time.  (Every rank takes the same decisions, so the two slots' exchanges would be
         // issued in the same order everywhere -- but that path has never run over RCCL on hardware: it stays off until
@@ -2058,8 +2093,14 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     HIPCHK(h, hipMemcpyAsync(dw.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemsetAsync(dinfo.p, 0, 4, s));
     HIPCHK(h, hipEventRecord(h->ev[14], s));
+    DevBuf dflags;
+    if ((rc = dev_alloc(h, dflags, 4 * SRK_SYNC_WORDS)) != SRK_OK) return rc;
+    HIPCHK(h, hipMemsetAsync(dflags.p, 0, 4 * SRK_SYNC_WORDS, s));
+    SrkCholSync sync;
+    sync.flags = P<unsigned>(dflags);
+    sync.fused = h->chol_fused;
     srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr, nullptr,
-                   P<double>(ddinv), nullptr);
+                   P<double>(ddinv), nullptr, &sync);
     HIPCHK(h, hipEventRecord(h->ev[15], s));
     HIPCHK(h, hipGetLastError());
     int info = 0;
@@ -2072,7 +2113,7 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
         *ms_factor = ms;
     }
     std::memcpy(x, bp.data(), (size_t)(8 * n));
-    dev_free(dA); dev_free(dw); dev_free(dy); dev_free(dx); dev_free(dinfo); dev_free(ddinv);
+    dev_free(dA); dev_free(dw); dev_free(dy); dev_free(dx); dev_free(dinfo); dev_free(ddinv); dev_free(dflags);
     return info ? 1 : 0;
 }
 
@@ -2122,6 +2163,17 @@ double srk_ba_solve_mfma_flops(srk_ba* h)
     launch_solve(h, &dry);
     return dry.flops;
 }
+
+// 1 (default) = an outer step of the blocked Cholesky is ONE launch whose workgroups hand tiles to each other (k_step256),
+// 0 = the k_panel / k_upd64 launch sequence.  Bit-identical results; takes effect at once.
+int srk_ba_set_solver_fusion(srk_ba* h, int on)
+{
+    if (!h || (on != 0 && on != 1)) return SRK_E_ARGS;
+    h->chol_fused = on != 0;
+    for (auto& a : h->att) a.sync.fused = h->chol_fused;
+    return SRK_OK;
+}
+int64_t srk_ba_solver_sync_timeouts(srk_ba* h) { return h ? h->sync_timeouts : -1; }
 
 int srk_ba_set_speculation(srk_ba* h, int on)
 {

@@ -168,6 +168,10 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
         sD[i][c] = v;
     }
     lds_barrier();
+    // what a sweep multiplies by is 1 / L_tt formed from the STORED L_tt: a workgroup that receives the factored tile from
+    // another one (k_step256) computes exactly this, so the fused and the unfused launch sequences agree bit for bit
+    if (t < NB) sInv[t] = fast_rcp(sD[t][t]);
+    lds_barrier();
     return !(dmin > 0.0) || (dchk != 0.0);
 }
 
@@ -514,6 +518,282 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
             for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
 }
 
+// ---------------------------------------------------------------- fused outer step: the four inner panels in ONE launch
+// The k_panel / k_upd64 sequence costs an outer step 4 x 20 + 3 x 8.5 us although its critical path -- factor tile d,
+// sweep the 64 rows of tile d + 1, update tile (d + 1, d + 1), factor it -- is ~17 us a tile: every panel launch loads,
+// factors the diagonal tile redundantly in every workgroup, sweeps ALL rows and stores before the update launch may
+// start.  k_step256 runs the whole outer step as one launch of workgroups with roles, ordered by blockIdx.x so that a
+// workgroup only ever waits for workgroups of LOWER index of its own item (blockIdx.z):
+//   x = 0..3  diagonal workgroup t: the 64 rows of tile row t of the 256 x 256 diagonal block.  Sub-steps d < t: it sweeps
+//             its rows against L_dd, PUBLISHES X_td (= L's tile (t, d), in place in A), applies the rank-64 update to its
+//             tiles (t, d + 1 .. t); sub-step t: factors its diagonal tile (the last update went straight into LDS),
+//             publishes L_tt, forms y_t = L_tt^-1 w_t and publishes it.
+//   x = 4     inverse workgroup: L_dd^-1 of the four tiles as they appear (for the backward substitution).
+//   x >= 5    row workgroups: 64 rows each of the rows below the diagonal block (skyline rows, then the live border rows);
+//             per sub-step: wait for L_dd, sweep, wait for y_d and X_td (t > d), update w and the tiles (., d + 1 .. 3).
+// Hand-offs follow the guide's recipe (cdna_hip_programming.md, Guideline 16 R1): payload stored write-through (sc1
+// stores), every storing wave drains, workgroup barrier, ONE lane stores the flag (sc1); the consumer polls that word
+// relaxed from one lane, ONE agent-scope acquire, barrier, then plain loads.  A flag word holds the EPOCH of the launch
+// that set it (the host counts launches per stream), so nothing is ever reset.  Every spin is bounded: a timeout sets
+// bit 8 of *info and the workgroup carries on (wrong numbers, flagged; the host repeats the solve with the unfused
+// kernels).  Deadlock: dispatch is in order of the linear workgroup index per XCD and a workgroup waits only for lower
+// indices, so the lowest unfinished index is always resident or first in line; the host keeps a launch within 256
+// workgroups, so that two of them (the two attempt slots) cannot fill an XCD with waiting workgroups.
+// Arithmetic: that of k_panel / k_upd64 (same potrf64, same sweep, same MFMA update order per tile).
+#define ST_F(d) (d)                                 // flag words of an item: L_dd published
+#define ST_Y(d) (4 + (d))                           // y_d published
+#define ST_G(t, d) (8 + (t) * ((t) - 1) / 2 + (d))  // X_td published, 1 <= t <= 3, d < t
+#define ST_WORDS 16
+#define ST_SPIN_MAX (1 << 17)
+typedef unsigned int __attribute__((address_space(1))) gu32_t;
+__device__ __forceinline__ void st_store(double* p, double v) // write-through store (global_store_dwordx2 sc1)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) // l: wave-uniform
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void st_publish(unsigned* f, unsigned epoch)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until every flag word of `mask` holds `epoch`; one lane polls, one acquire, then the workgroup's barrier
+__device__ __forceinline__ void st_wait(unsigned* fl, unsigned mask, unsigned epoch, int* info)
+{
+    if (threadIdx.x == 0) {
+        unsigned pending = mask;
+        int spins = 0;
+        while (pending) {
+            const int k = __ffs(pending) - 1;
+            if (__hip_atomic_load(fl + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+                pending &= pending - 1;
+                continue;
+            }
+            if (++spins > ST_SPIN_MAX) { atomicOr(info, 8); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+// 64 x 64 tile at T (row stride ld) -> sD; lower: zeros above the diagonal
+template <bool LOWER> __device__ __forceinline__ void st_load_tile(double (*sD)[NB + 2], const double* __restrict__ T, int64_t ld)
+{
+    const int i = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
+    const double2* src = reinterpret_cast<const double2*>(T + (int64_t)i * ld + cb);
+    double2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = src[t];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int c = cb + 2 * t;
+        sD[i][c] = (!LOWER || c <= i) ? v[t].x : 0.0;
+        sD[i][c + 1] = (!LOWER || c + 1 <= i) ? v[t].y : 0.0;
+    }
+}
+__global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                     int64_t K, unsigned* __restrict__ flags, unsigned epoch, int* __restrict__ info)
+{
+    const int z = blockIdx.z;
+    const int64_t row_end = rend.v[z];
+    if (row_end < 0) return;
+    double* __restrict__ A = B.it[z].A;
+    double* __restrict__ w = B.it[z].w;
+    double* __restrict__ y = B.it[z].y;
+    const int64_t ld = B.it[z].ld, k0 = K * NBO;
+    unsigned* fl = flags + ST_WORDS * z;
+    const int role = blockIdx.x, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
+    __shared__ __attribute__((aligned(16))) double sA[NB][NB + 2]; // own X of this sub-step (MFMA A operand); inverse role: sZ
+    __shared__ double sT[32][33];                                  // inverse role only
+    __shared__ __attribute__((aligned(16))) double sCol[8 * NB];
+    __shared__ double sDiag[NB];
+    __shared__ double sInv[NB];
+    __shared__ double sy[NB];
+    static_assert(sizeof(double) * NB * (NB + 2) >= sizeof(double) * NB * (NB + 1), "sZ fits sA");
+    if (role == 4) { // ---- inverses of the diagonal tiles, as they are published
+        for (int d = 0; d < NBO / NB; ++d) {
+            st_wait(fl, 1u << ST_F(d), epoch, info);
+            st_load_tile<true>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
+            __syncthreads();
+            tile_inverse(sD, reinterpret_cast<double (*)[NB + 1]>(&sA[0][0]), sT, sDiag, B.it[z].dinv + (K * (NBO / NB) + d) * NB * NB);
+            __syncthreads();
+        }
+        return;
+    }
+    int mytile;
+    int64_t r0;
+    if (role < 4) {
+        mytile = role;
+        r0 = k0 + role * NB;
+    } else {
+        int64_t n1 = (row_end - (k0 + NBO)) / NB;
+        if (n1 < 0) n1 = 0;
+        const int64_t r2_begin = r2b.v[z], n2 = (r2e.v[z] - r2_begin) / NB, ridx = role - 5;
+        if (ridx >= n1 + n2) return;
+        mytile = 4;
+        r0 = ridx < n1 ? k0 + NBO + ridx * NB : r2_begin + (ridx - n1) * NB;
+    }
+    const int i = tid >> 2, q = tid & 3;
+    double* rowp = A + (r0 + i) * ld + k0; // this thread's row, first column of the outer block
+    double wi = q == 0 ? w[r0 + i] : 0.0;
+    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
+    for (int d = 0; d < NBO / NB; ++d) {
+        if (d == mytile) {
+            // ---- this workgroup's diagonal tile: every update has been applied (the last one went into sD)
+            if (d == 0) {
+                st_load_tile<true>(sD, A + r0 * ld + k0, ld);
+                __syncthreads();
+            }
+            const bool bad = potrf64(sD, sCol, sDiag, sInv);
+            if (bad && tid == 0) atomicOr(info, 1);
+            {
+                const int cb = q * 16;
+                double* dst = A + (r0 + i) * ld + k0 + d * NB + cb;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) st_store(dst + c, sD[i][cb + c]);
+            }
+            st_publish(fl + ST_F(d), epoch);
+            // y_d = L_dd^-1 w_d: one wave, lane = row, 64 dependent steps
+            if (q == 0) sy[i] = wi;
+            __syncthreads();
+            if (tid < NB) {
+                double v = sy[tid];
+                const double myinv = sInv[tid];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    v = tid == j ? v * myinv : v; // y_j, on lane j
+                    const double yj = readlane_f64(v, j);
+                    v = tid > j ? fma(-sD[tid][j], yj, v) : v;
+                }
+                st_store(y + k0 + d * NB + tid, v);
+            }
+            st_publish(fl + ST_Y(d), epoch);
+            return;
+        }
+        // ---- a sweeping sub-step (d < mytile): X = A[rows, tile d] L_dd^-T
+        double a[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) a[m] = rowp[d * NB + 4 * m + q]; // own data (earlier kernels / this workgroup's updates)
+        st_wait(fl, 1u << ST_F(d), epoch, info);
+        st_load_tile<false>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
+        __syncthreads();
+        if (tid < NB) sInv[tid] = fast_rcp(sD[tid][tid]);
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int c0 = 4 * b;
+            double v0 = quad_bcast<0>(a[b]), v1 = quad_bcast<1>(a[b]), v2 = quad_bcast<2>(a[b]), v3 = quad_bcast<3>(a[b]);
+            double x0 = v0 * sInv[c0];
+            double x1 = fma(-x0, sD[c0 + 1][c0], v1) * sInv[c0 + 1];
+            double x2 = fma(-x1, sD[c0 + 2][c0 + 1], fma(-x0, sD[c0 + 2][c0], v2)) * sInv[c0 + 2];
+            double x3 = fma(-x2, sD[c0 + 3][c0 + 2], fma(-x1, sD[c0 + 3][c0 + 1], fma(-x0, sD[c0 + 3][c0], v3))) * sInv[c0 + 3];
+            {
+                const double x01 = (q & 1) ? x1 : x0, x23 = (q & 1) ? x3 : x2;
+                a[b] = (q & 2) ? x23 : x01;
+            }
+#pragma unroll
+            for (int m = b + 1; m < 16; ++m) {
+                const double2* lp = reinterpret_cast<const double2*>(&sD[4 * m + q][c0]);
+                double2 l01 = lp[0], l23 = lp[1];
+                a[m] = fma(-x3, l23.y, fma(-x2, l23.x, fma(-x1, l01.y, fma(-x0, l01.x, a[m]))));
+                if (((m - b) & 3) == 0) asm volatile("" ::: "memory");
+            }
+            asm volatile("" ::: "memory");
+        }
+        // X is final: to its place in A (a diagonal workgroup publishes it) and to sA as the updates' A operand
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sA[i][4 * m + q] = a[m];
+        unsigned need = 1u << ST_Y(d);
+        if (mytile < 4) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) st_store(rowp + d * NB + 4 * m + q, a[m]);
+            st_publish(fl + ST_G(mytile, d), epoch);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) rowp[d * NB + 4 * m + q] = a[m];
+        }
+        const int tmax = mytile < 4 ? mytile : NBO / NB - 1;
+        for (int t = d + 1; t <= tmax; ++t)
+            if (t != mytile) need |= 1u << ST_G(t, d);
+        st_wait(fl, need, epoch, info); // (its barrier also orders sA's writes and the last reads of sD)
+        // forward substitution's update of this workgroup's rows: w_r -= X[r, tile d] . y_d
+        if (tid < NB) sy[tid] = y[k0 + d * NB + tid];
+        __syncthreads();
+        {
+            double dot = 0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) dot = fma(a[m], sy[4 * m + q], dot);
+            dot += __shfl_xor(dot, 1, 64);
+            dot += __shfl_xor(dot, 2, 64);
+            wi -= dot;
+        }
+        // rank-64 update of this workgroup's tiles (., t), t = d + 1 .. tmax:  C -= X X_td^T
+        for (int t = d + 1; t <= tmax; ++t) {
+            const bool own = t == mytile;             // the diagonal tile of a diagonal workgroup: B operand = its own X
+            const bool to_lds = own && d + 1 == mytile; // its last update: the result is what potrf64 factors next
+            double (*sB)[NB + 2] = own ? sA : sD;
+            if (!own) {
+                __syncthreads(); // every wave is done with the previous contents of sD
+                st_load_tile<false>(sD, A + (k0 + t * NB) * ld + k0 + d * NB, ld);
+            }
+            double* pc0 = A + (r0 + wr * 32 + lk) * ld + k0 + t * NB + wc * 32 + lr;
+            double cv[2][2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) cv[m][n][reg] = pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16];
+            __syncthreads();
+            double4_t acc[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){ 0, 0, 0, 0 };
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; ++kk) {
+                const double a0 = sA[wr * 32 + lr][kk * 4 + lk];
+                const double a1 = sA[wr * 32 + 16 + lr][kk * 4 + lk];
+                const double b0 = sB[wc * 32 + lr][kk * 4 + lk];
+                const double b1 = sB[wc * 32 + 16 + lr][kk * 4 + lk];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (to_lds) {
+                __syncthreads(); // (own: the operands were read from sA; sD may still be read by a slower wave of the previous t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int rr = wr * 32 + m * 16 + 4 * reg + lk, cc = wc * 32 + n * 16 + lr;
+                            sD[rr][cc] = cc <= rr ? cv[m][n][reg] - acc[m][n][reg] : 0.0;
+                        }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
+            }
+        }
+        __syncthreads(); // the updates' stores are complete before the next sub-step loads its columns; sD is free
+    }
+    if (q == 0) w[r0 + i] = wi; // (row workgroups; a diagonal workgroup's w_t became y_t)
+}
+
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
 // C[ti, tj] -= P[ti] P[tj]^T over the 128x128 tile pairs ti >= tj of rows/cols [c_first, row_end), P = the 256
 // panel columns starting at k0.  One workgroup per tile pair (linear index -> triangular pair).
@@ -795,7 +1075,8 @@ __global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholSte
 // [r2_begin, r2_end) (multiples of 128; empty when r2_begin == r2_end).  The forward substitution of w rides along
 // (k_panel); y receives L^-1 w for the eliminated columns, the border part of w its Schur-complement update.
 // Items advance in lock step: launch K serves outer panel K of every item that has one.
-static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, int* d_info, SrkSolveProf* prof)
+static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, int* d_info, SrkSolveProf* prof,
+                        SrkCholSync* sync)
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
@@ -819,7 +1100,22 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
                 if (r2e.v[i] < r2b.v[i]) r2e.v[i] = r2b.v[i];
             }
         }
-        for (int jsub = 0; jsub < NBO / NB; ++jsub) {
+        // the four inner panels as ONE launch (k_step256) when its workgroups stay within one wave of the chip
+        int64_t row_wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            if (st.v[i] < 0) continue;
+            int64_t n1 = (st.v[i] - (k0 + NBO)) / NB;
+            if (n1 < 0) n1 = 0;
+            row_wgs = std::max(row_wgs, n1 + (r2e.v[i] - r2b.v[i]) / NB);
+        }
+        const bool fused = sync && sync->flags && sync->fused && (5 + row_wgs) * n <= 256;
+        if (fused) {
+            ++sync->epoch;
+            if (sync->epoch == 0) ++sync->epoch; // the flag words start at 0
+            LAUNCH(k_step256, dim3((unsigned)(5 + row_wgs), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, K, sync->flags,
+                   sync->epoch, d_info);
+        }
+        for (int jsub = 0; jsub < NBO / NB && !fused; ++jsub) {
             const int64_t d = K * (NBO / NB) + jsub;
             int64_t blocks = 0, tiles = 0;
             for (int i = 0; i < n; ++i) {
@@ -895,14 +1191,14 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
 // columns and are skipped; NULL = dense.  col_begin[d64] (host, per 64-tile, may be NULL): first column with a
 // non-zero in tile row d64.  dinv: scratch, (ld / 64) * 64 * 64 doubles (inverses of the diagonal tiles).
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
-                    const int64_t* row_end, const int64_t* col_begin, double* dinv, SrkSolveProf* prof)
+                    const int64_t* row_end, const int64_t* col_begin, double* dinv, SrkSolveProf* prof, SrkCholSync* sync)
 {
     CholBatch B{};
     B.it[0] = CholItem{ A, w, y, x, dinv, ld, ld, ld, ld };
     CholHostItem H;
     H.row_end = row_end;
     H.col_begin = col_begin;
-    chol_factor(s, B, 1, &H, d_info, prof);
+    chol_factor(s, B, 1, &H, d_info, prof, sync);
     chol_bwd(s, B, 1, &H, prof, d_info); // every variable is written by a k_bwd256 step, which checks it
 }
 
@@ -1062,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, in
 }
 
 static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs, double* x,
-                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, bool top)
+                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, bool top, SrkCholSync* sync)
 {
     const int P = pl.P;
     const int64_t sepw = pl.sepw, lds = pl.lds;
@@ -1092,12 +1388,12 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
     const int64_t tile0 = (std::max(max_ldc, lds) + GATHER_ROWS - 1) / GATHER_ROWS;
     LAUNCH(k_level_gather, dim3((unsigned)(tile0 + (sepw / 64) * (sepw / 64)), 1, (unsigned)(P + 1)), dim3(256), 0, s, S, ld,
            rhs, d_env_col, B, first, sepw, P, pl.d_sep_start, pl.Cs, lds, pl.ws, tile0);
-    chol_factor(s, B, P, H, d_info, prof);
+    chol_factor(s, B, P, H, d_info, prof, sync);
     LAUNCH(k_sep_reduce, dim3((unsigned)lds), dim3(256), 0, s, B, sepw, pl.Cs, lds, pl.ws);
     if (pl.child) { // the separator system is block tridiagonal: chunk it again
-        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof, false);
+        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof, false, sync);
     } else {
-        chol_factor(s, Bs, 1, &Hs, d_info, prof);
+        chol_factor(s, Bs, 1, &Hs, d_info, prof, sync);
         chol_bwd(s, Bs, 1, &Hs, prof, nullptr);
     }
     int* d_finite = top ? d_info : nullptr;
@@ -1107,8 +1403,8 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
-                            double* x, const int64_t* d_env_col, int* d_info, SrkSolveProf* prof)
+                            double* x, const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, SrkCholSync* sync)
 {
     // every variable of the system is a chunk or a separator variable of the top level: its backward kernels check them all
-    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true);
+    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true, sync);
 }

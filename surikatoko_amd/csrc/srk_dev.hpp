@@ -125,6 +125,15 @@ struct SrkSolveProf {
     bool dry = false;
 };
 
+// state of the fused outer-step kernel's in-launch hand-offs (k_step256): flag words (device, zeroed once, 16 per batch
+// item) that hold the epoch of the launch that set them, and the host's launch counter.  One per stream.
+#define SRK_SYNC_WORDS (16 * 32) // 16 words x SRK_MAX_CHUNKS items
+struct SrkCholSync {
+    unsigned* flags = nullptr;
+    unsigned epoch = 0;
+    bool fused = true; // false: the unfused k_panel / k_upd64 sequence
+};
+
 // ---- dense SPD solver (srk_chol.hip) ----
 // In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) with the forward
 // substitution folded in, then the backward substitution.  w: rhs (destroyed), y: scratch, x: solution.
@@ -132,7 +141,7 @@ struct SrkSolveProf {
 // row_end / col_begin: optional host arrays describing the skyline of A (see srk_chol.hip); NULL = dense.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
                     const int64_t* row_end, const int64_t* col_begin, double* dinv /* (ld / 64) * 4096 doubles */,
-                    struct SrkSolveProf* prof /* may be NULL */);
+                    struct SrkSolveProf* prof /* may be NULL */, struct SrkCholSync* sync /* NULL: unfused kernels */);
 
 // ---- chunked (bordered block-diagonal) solve of a banded reduced camera system (srk_chol.hip) ----
 #include <vector>
@@ -158,4 +167,5 @@ struct SrkChunkPlan {
     SrkChunkPlan* child = nullptr;   // plan of the separator system itself (nested dissection); NULL = direct solve
 };
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
-                            double* x, const int64_t* d_env_col, int* d_info, struct SrkSolveProf* prof /* may be NULL */);
+                            double* x, const int64_t* d_env_col, int* d_info, struct SrkSolveProf* prof /* may be NULL */,
+                            struct SrkCholSync* sync /* NULL: unfused kernels */);

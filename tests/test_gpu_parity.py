@@ -888,6 +888,58 @@ def test_nested_plan_edge_sizes(gpu, n_frames):
     assert rel_err(dc, x) < 1e-9, (n_frames, gpu.rcs_chunks())
 
 
+def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_dense(gpu):
+    """k_step256 (an outer step of the blocked Cholesky as ONE launch whose workgroups hand tiles to one another) against
+    the k_panel / k_upd64 launch sequence it replaces: same arithmetic in the same order, so the solutions must be
+    IDENTICAL.  Dense systems of one to five outer steps; repeated, so that a stale read of a handed-off tile would have
+    several chances to show."""
+    rng = np.random.RandomState(5)
+    try:
+        for n in (200, 256, 300, 777, 1280):
+            A = rng.randn(n, n)
+            A = A @ A.T + n * np.eye(n) + np.diag(np.arange(n) * 0.37)
+            b = rng.randn(n)
+            sols = {}
+            for fused in (1, 0, 1, 1, 1):
+                gpu.set_solver_fusion(fused)
+                ok, x, _ = gpu.dense_spd_solve(A, b)
+                assert ok
+                if fused in sols:
+                    assert np.array_equal(x, sols[fused]), n
+                sols[fused] = x
+            assert np.array_equal(sols[1], sols[0]), n
+            assert np.abs(sols[1] - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
+        assert gpu.solver_sync_timeouts() == 0
+    finally:
+        gpu.set_solver_fusion(1)
+
+
+@pytest.mark.parametrize("n_frames,window", [(103, 8), (330, 8), (500, 30), (800, 95)])
+def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_frames, window):
+    """The same on nested chunks with 256- to 1024-wide separators (batched items, border rows, structurally zero border
+    rows skipped per step): the chunked solve works on copies, so the SAME reduced camera system is solved both ways."""
+    spec = sa.SceneSpec(n_frames=n_frames, grid_nx=60, grid_ny=40, vis_window=window)
+    sc = sa.generate_scene(spec)
+    try:
+        assert gpu.upload(spec.f0, sc)
+        assert gpu.rcs_chunks() >= 2
+        gpu.phase_derivatives()
+        gpu.phase_schur(1e-3)
+        sols = {}
+        for fused in (1, 0, 1, 1, 1):
+            gpu.set_solver_fusion(fused)
+            assert gpu.phase_solve()
+            x = gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:]
+            assert np.all(np.isfinite(x))
+            if fused in sols:
+                assert np.array_equal(x, sols[fused])
+            sols[fused] = x
+        assert np.array_equal(sols[1], sols[0])
+        assert gpu.solver_sync_timeouts() == 0
+    finally:
+        gpu.set_solver_fusion(1)
+
+
 def test_chunked_end_to_end_matches_single_chain(gpu):
     spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
     sc = sa.generate_scene(spec)
