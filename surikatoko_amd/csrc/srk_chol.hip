@@ -550,6 +550,11 @@ __device__ __forceinline__ void st_store(double* p, double v) // write-through s
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_store16(double* p, dbl2_t v) // 16-byte write-through store
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ double readlane_f64(double v, int l) // l: wave-uniform
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -598,6 +603,13 @@ template <bool LOWER> __device__ __forceinline__ void st_load_tile(double (*sD)[
         sD[i][c + 1] = (!LOWER || c + 1 <= i) ? v[t].y : 0.0;
     }
 }
+#ifdef SRK_STEP_STAMPS // development (tools/step_stamps.sh): wall-clock stamps of item 0's workgroups of one launch
+__device__ long long g_step_stamps[8][32];
+#define SST(k) do { if (blockIdx.z == 0 && K == 0 && threadIdx.x == 0 && blockIdx.x < 8) g_step_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
+extern "C" void srk_dbg_step_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_stamps), sizeof(long long) * 256); }
+#else
+#define SST(k)
+#endif
 __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
                                                      int64_t K, unsigned* __restrict__ flags, unsigned epoch, int* __restrict__ info)
 {
@@ -645,22 +657,48 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
     double* rowp = A + (r0 + i) * ld + k0; // this thread's row, first column of the outer block
     double wi = q == 0 ? w[r0 + i] : 0.0;
     const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
+    // forward substitution's update of this workgroup's rows with the PREVIOUS sub-step's panel, w_r -= X[r, tile p] . y_p:
+    // y_p appears a few microseconds after L_pp, so its wait rides on the next wait this workgroup has anyway; X of the
+    // previous sub-step is still in sA then
+    auto w_update = [&](int p) {
+        if (tid < NB) sy[tid] = y[k0 + p * NB + tid];
+        __syncthreads();
+        double dot = 0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) dot = fma(sA[i][4 * m + q], sy[4 * m + q], dot);
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        wi -= dot;
+    };
+    // a 64 x 64 tile from LDS to global memory, write-through and coalesced (a wave stores four whole rows at a time)
+    auto publish_tile = [&](const double (*sX)[NB + 2], double* T) {
+        const int r = tid >> 5, c = (tid & 31) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double2 v = *reinterpret_cast<const double2*>(&sX[r + 8 * k][c]);
+            st_store16(T + (int64_t)(r + 8 * k) * ld + c, (dbl2_t){ v.x, v.y });
+        }
+    };
+    SST(0);
     for (int d = 0; d < NBO / NB; ++d) {
         if (d == mytile) {
+            SST(1 + 6 * d);
             // ---- this workgroup's diagonal tile: every update has been applied (the last one went into sD)
             if (d == 0) {
                 st_load_tile<true>(sD, A + r0 * ld + k0, ld);
                 __syncthreads();
             }
             const bool bad = potrf64(sD, sCol, sDiag, sInv);
+            SST(2 + 6 * d);
             if (bad && tid == 0) atomicOr(info, 1);
-            {
-                const int cb = q * 16;
-                double* dst = A + (r0 + i) * ld + k0 + d * NB + cb;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) st_store(dst + c, sD[i][cb + c]);
-            }
+            publish_tile(sD, A + r0 * ld + k0 + d * NB);
             st_publish(fl + ST_F(d), epoch);
+            SST(3 + 6 * d);
+            if (d > 0) { // the pending update of w_d with y_(d-1)
+                st_wait(fl, 1u << ST_Y(d - 1), epoch, info);
+                w_update(d - 1);
+                __syncthreads(); // sy is rewritten next
+            }
             // y_d = L_dd^-1 w_d: one wave, lane = row, 64 dependent steps
             if (q == 0) sy[i] = wi;
             __syncthreads();
@@ -676,17 +714,22 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
                 st_store(y + k0 + d * NB + tid, v);
             }
             st_publish(fl + ST_Y(d), epoch);
+            SST(4 + 6 * d);
             return;
         }
         // ---- a sweeping sub-step (d < mytile): X = A[rows, tile d] L_dd^-T
         double a[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) a[m] = rowp[d * NB + 4 * m + q]; // own data (earlier kernels / this workgroup's updates)
-        st_wait(fl, 1u << ST_F(d), epoch, info);
+        SST(1 + 6 * d);
+        st_wait(fl, (1u << ST_F(d)) | (d > 0 ? 1u << ST_Y(d - 1) : 0u), epoch, info);
+        SST(2 + 6 * d);
+        if (d > 0) w_update(d - 1);
         st_load_tile<false>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
         __syncthreads();
         if (tid < NB) sInv[tid] = fast_rcp(sD[tid][tid]);
         __syncthreads();
+        SST(3 + 6 * d);
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const int c0 = 4 * b;
@@ -708,42 +751,41 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
             }
             asm volatile("" ::: "memory");
         }
-        // X is final: to its place in A (a diagonal workgroup publishes it) and to sA as the updates' A operand
+        SST(4 + 6 * d);
+        // X is final: to sA (the updates' A operand; the next w update reads it there) and to its place in A -- a diagonal
+        // workgroup publishes it (coalesced, from sA), a row workgroup stores it plainly
 #pragma unroll
         for (int m = 0; m < 16; ++m) sA[i][4 * m + q] = a[m];
-        unsigned need = 1u << ST_Y(d);
+        const int tmax = mytile < 4 ? mytile : NBO / NB - 1;
+        unsigned need = 0;
+        for (int t = d + 1; t <= tmax; ++t)
+            if (t != mytile) need |= 1u << ST_G(t, d);
         if (mytile < 4) {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) st_store(rowp + d * NB + 4 * m + q, a[m]);
+            __syncthreads();
+            publish_tile(sA, A + r0 * ld + k0 + d * NB);
             st_publish(fl + ST_G(mytile, d), epoch);
         } else {
 #pragma unroll
             for (int m = 0; m < 16; ++m) rowp[d * NB + 4 * m + q] = a[m];
         }
-        const int tmax = mytile < 4 ? mytile : NBO / NB - 1;
-        for (int t = d + 1; t <= tmax; ++t)
-            if (t != mytile) need |= 1u << ST_G(t, d);
-        st_wait(fl, need, epoch, info); // (its barrier also orders sA's writes and the last reads of sD)
-        // forward substitution's update of this workgroup's rows: w_r -= X[r, tile d] . y_d
-        if (tid < NB) sy[tid] = y[k0 + d * NB + tid];
-        __syncthreads();
-        {
-            double dot = 0;
+        SST(5 + 6 * d);
+        if (need) st_wait(fl, need, epoch, info);
+        else __syncthreads(); // sA is written; every wave is done with L_dd in sD
+        SST(6 + 6 * d);
+        // rank-64 update of this workgroup's tiles (., t), t = d + 1 .. tmax:  C -= X X_td^T.  The B operand X_td of the next
+        // tile is fetched into registers while this one is multiplied.
+        const int bi = tid >> 2, bc = (tid & 3) * 16;
+        double2 bv[8];
+        auto fetch_b = [&](int t) {
+            const double2* src = reinterpret_cast<const double2*>(A + (k0 + t * NB + bi) * ld + k0 + d * NB + bc);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) dot = fma(a[m], sy[4 * m + q], dot);
-            dot += __shfl_xor(dot, 1, 64);
-            dot += __shfl_xor(dot, 2, 64);
-            wi -= dot;
-        }
-        // rank-64 update of this workgroup's tiles (., t), t = d + 1 .. tmax:  C -= X X_td^T
+            for (int k = 0; k < 8; ++k) bv[k] = src[k];
+        };
+        if (d + 1 <= tmax && d + 1 != mytile) fetch_b(d + 1);
         for (int t = d + 1; t <= tmax; ++t) {
-            const bool own = t == mytile;             // the diagonal tile of a diagonal workgroup: B operand = its own X
+            const bool own = t == mytile;               // the diagonal tile of a diagonal workgroup: B operand = its own X
             const bool to_lds = own && d + 1 == mytile; // its last update: the result is what potrf64 factors next
             double (*sB)[NB + 2] = own ? sA : sD;
-            if (!own) {
-                __syncthreads(); // every wave is done with the previous contents of sD
-                st_load_tile<false>(sD, A + (k0 + t * NB) * ld + k0 + d * NB, ld);
-            }
             double* pc0 = A + (r0 + wr * 32 + lk) * ld + k0 + t * NB + wc * 32 + lr;
             double cv[2][2][4];
 #pragma unroll
@@ -752,7 +794,16 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) cv[m][n][reg] = pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16];
-            __syncthreads();
+            if (!own) {
+                if (t > d + 1) __syncthreads(); // every wave is done with the previous B tile in sD
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    sD[bi][bc + 2 * k] = bv[k].x;
+                    sD[bi][bc + 2 * k + 1] = bv[k].y;
+                }
+                __syncthreads();
+                if (t + 1 <= tmax && t + 1 != mytile) fetch_b(t + 1);
+            }
             double4_t acc[2][2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -770,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
                 acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
             }
             if (to_lds) {
-                __syncthreads(); // (own: the operands were read from sA; sD may still be read by a slower wave of the previous t)
+                __syncthreads(); // (a slower wave may still read the previous B tile in sD)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -791,7 +842,11 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
         }
         __syncthreads(); // the updates' stores are complete before the next sub-step loads its columns; sD is free
     }
-    if (q == 0) w[r0 + i] = wi; // (row workgroups; a diagonal workgroup's w_t became y_t)
+    // (row workgroups only; a diagonal workgroup's w_t became y_t)
+    st_wait(fl, 1u << ST_Y(NBO / NB - 1), epoch, info);
+    w_update(NBO / NB - 1);
+    SST(25);
+    if (q == 0) w[r0 + i] = wi;
 }
 
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
