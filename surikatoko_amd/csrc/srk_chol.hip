@@ -580,7 +580,11 @@ __device__ __forceinline__ void st_wait(unsigned* fl, unsigned mask, unsigned ep
                 pending &= pending - 1;
                 continue;
             }
-            if (++spins > ST_SPIN_MAX) { atomicOr(info, 8); break; }
+            // (bounded; and once any workgroup has given up, nobody waits out its own bound)
+            if (++spins > ST_SPIN_MAX || ((spins & 63) == 0 && (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8))) {
+                atomicOr(info, 8);
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -603,6 +607,10 @@ template <bool LOWER> __device__ __forceinline__ void st_load_tile(double (*sD)[
         sD[i][c + 1] = (!LOWER || c + 1 <= i) ? v[t].y : 0.0;
     }
 }
+// test hook (srk_dbg_step_fault): the next N launches' first diagonal workgroup of item 0 does not publish L_00 -- every
+// consumer of that item runs into its spin bound, bit 8 of *info is set and the host repeats the solve unfused
+__device__ int g_step_fault = 0;
+extern "C" void srk_dbg_step_fault(int launches) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_fault), &launches, sizeof(int)); }
 #ifdef SRK_STEP_STAMPS // development (tools/step_stamps.sh): wall-clock stamps of item 0's workgroups of one launch
 __device__ long long g_step_stamps[8][32];
 #define SST(k) do { if (blockIdx.z == 0 && K == 0 && threadIdx.x == 0 && blockIdx.x < 8) g_step_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
@@ -692,6 +700,11 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
             SST(2 + 6 * d);
             if (bad && tid == 0) atomicOr(info, 1);
             publish_tile(sD, A + r0 * ld + k0 + d * NB);
+            if (d == 0 && z == 0 && g_step_fault > 0) { // (test hook: a lost hand-off)
+                __syncthreads();
+                if (tid == 0) atomicSub(&g_step_fault, 1);
+                return;
+            }
             st_publish(fl + ST_F(d), epoch);
             SST(3 + 6 * d);
             if (d > 0) { // the pending update of w_d with y_(d-1)

@@ -940,6 +940,31 @@ def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_f
         gpu.set_solver_fusion(1)
 
 
+def test_a_lost_hand_off_times_out_and_the_attempt_is_repeated_with_the_panel_sequence(gpu):
+    """Every wait inside k_step256 is bounded.  Test hook: one launch's first diagonal workgroup does not publish its tile;
+    its consumers give up, the solve reports bit 8, the LM loop repeats that attempt with the unfused kernels (and stays
+    there) -- same iterations, attempts and numbers as an undisturbed run."""
+    spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
+    sc = sa.generate_scene(spec)
+    try:
+        gpu.set_solver_fusion(1)
+        s1 = sc.copy()
+        gpu.ComputeInplace(spec.f0, s1, None, 3)
+        ref = (gpu.report.iterations, gpu.report.attempts, gpu.report.err_final)
+        before = gpu.solver_sync_timeouts()
+        sa.lib().srk_dbg_step_fault(1)
+        s2 = sc.copy()
+        gpu.ComputeInplace(spec.f0, s2, None, 3)
+        assert gpu.solver_sync_timeouts() == before + 1
+        assert (gpu.report.iterations, gpu.report.attempts) == ref[:2]
+        assert gpu.report.err_final == pytest.approx(ref[2], rel=1e-9)
+        assert np.abs(s2.points - s1.points).max() < 1e-9
+        assert np.abs(s2.cam_T - s1.cam_T).max() < 1e-9
+    finally:
+        sa.lib().srk_dbg_step_fault(0)
+        gpu.set_solver_fusion(1)
+
+
 def test_chunked_end_to_end_matches_single_chain(gpu):
     spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
     sc = sa.generate_scene(spec)
