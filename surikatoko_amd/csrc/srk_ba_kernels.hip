@@ -1723,281 +1723,6 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #endif
 }
 
-// ------------------------------------------------------------------ K3m2: the same product, every wave multiplies
-// tools/ubench/mfma64_side.hip: while three waves of a SIMD issue v_mfma_f64_16x16x4 back to back, a fourth wave WITHOUT
-// MFMAs makes no progress at all -- k_schur_mm's four helper waves (one per SIMD) therefore ran only while the multiplying
-// waves stood at the round barrier, and their ~1 us of staging and Y arithmetic was ADDED to every 2.2 us round of MFMAs.
-// A wave's own vector-ALU / LDS instructions between its own MFMAs do issue (~4 cycles of MFMA time each,
-// mfma64_valu.hip).  So here all 16 waves multiply (six tiles each: 96 slots for the <= 91 tiles) and each carries one
-// sixteenth of the helpers' work inside its MFMA stream:
-//   staging   wave w moves the W planes k = 2w, 2w + 1 of the round's <= 80 observations (two loads per plane and lane,
-//             coalesced over the observations; round r + 3's loads are issued in round r, written to LDS in round r + 1);
-//   Y, rhs    wave w forms Y = E^-1 W of round r + 1 for landmark w / 4 of the round, columns 64 (w % 4) + lane.
-// Buffers, barrier and flush are k_schur_mm's (W triple-buffered, Y double-buffered, one LDS-only barrier a round).
-#define SRK_MM2_SLOTS 6
-template <typename WT>
-__global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm2(
-    SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
-    const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
-    const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
-    const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
-    const int32_t* __restrict__ grp_frames)
-{
-    constexpr int PB = SRK_GRP_PB;             // landmarks of a round
-    constexpr int KR = 3 * PB;                 // k rows of a round
-    constexpr int LDW = SRK_MM_LDW;            // row stride (doubles)
-    constexpr int WB = KR * LDW;               // one buffer: W or Y of a round
-    constexpr int CAP = 5 * WB;                // W0 | W1 | W2 | Y0 | Y1; the flush uses all of it
-    constexpr int QMAX = PB * SRK_WS_NF;       // observations of a round
-    constexpr int NW = SRK_MM_THREADS / 64;
-    constexpr int NS = SRK_MM2_SLOTS;
-    static_assert(PB == 4 && NW == 16 && QMAX <= 128 && 2 * (NW - 1) >= 30, "slices: one Y unit and two W planes per wave");
-    static_assert(NW * NS >= 13 * 14 / 2 && 4 * 64 >= SRK_WS_NF * 10, "tiles / columns do not fit the waves");
-    __shared__ __attribute__((aligned(16))) double sBuf[CAP];
-    __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
-    __shared__ double sRhs[SRK_WS_NF * 10];
-    __shared__ int32_t sVar[SRK_WS_NF * 10]; // row / column of S of the sum's row / column e; -1: a gauge-fixed variable
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifndef SRK_MM_NO_STAGGER
-    if (blockIdx.x < 256 && gridDim.x >= 512)
-        for (int t = (blockIdx.x >> 3) & 15; t > 0; --t) __builtin_amdgcn_s_sleep(127);
-#endif
-    const int64_t p0 = grp_first[blockIdx.x];
-    const int np = grp_count[blockIdx.x];
-    const int nfu = grp_nf[blockIdx.x];
-    const bool ragged = nfu < 0;
-    const int nf = ragged ? -nfu : nfu;
-    if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
-    if (tid < nf * 10) {
-        sRhs[tid] = 0.0;
-        const int64_t var = 10 * (int64_t)grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid / 10] + tid % 10;
-        sVar[tid] = srk_is_fixed_var(var, d.comp) ? -1 : (int)var;
-    }
-    const int R = (np + PB - 1) / PB;
-    const int nf10 = nf * 10;
-    const int64_t o0 = row_ptr[p0];
-    // rounds 0 and 1 are staged by the whole workgroup, their loads in flight together with the 3x3 blocks' below
-    {
-        const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
-        constexpr int NI = (2 * 30 * QMAX + SRK_MM_THREADS - 1) / SRK_MM_THREADS;
-        double v[NI];
-        int dst[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int e = tid + SRK_MM_THREADS * j;
-            const int rd = e / (30 * QMAX), rem = e - rd * (30 * QMAX);
-            const int k = rem / QMAX, q = rem - k * QMAX;
-            const int oa = rd ? o1 : 0, nq = rd ? o2 - o1 : o1;
-            dst[j] = -1;
-            v[j] = 0;
-            if (rd < 2 && q < nq) {
-                v[j] = W[(int64_t)k * d.Os + o0 + oa + q];
-                int pl, a;
-                if (ragged) { pl = obs_pt[o0 + oa + q] - (int)(p0 + rd * PB); a = (int)obs_slot[o0 + oa + q]; }
-                else { pl = q / nf; a = q - pl * nf; }
-                const int m = k / 10, rr = k - 10 * m;
-                dst[j] = rd * WB + (3 * pl + m) * LDW + 10 * a + rr;
-            }
-        }
-        if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
-            double Einv[9], g[3];
-            bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-                sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-            if (dst[j] >= 0) sBuf[dst[j]] = v[j];
-    }
-    constexpr int TR = CAP / (16 * LDW);
-    auto flush_stream = [&](int t0) { // rows 16 t0 .. 16 (t0 + TR) - 1
-        for (int rho = wv; rho < 16 * TR; rho += NW) {
-            const int Rr = 16 * t0 + rho;
-            if (Rr >= nf10) break;
-            const int row = sVar[Rr];
-            if (row < 0) continue;
-            const double* src = sBuf + rho * LDW;
-            double* dstp = S + (int64_t)row * d.ld;
-            const int w = 10 * (Rr / 10 + 1);
-            for (int cw = lane; cw < w; cw += 64) {
-                const int col = sVar[cw];
-                if (col < 0) continue;
-                atomicAdd(&dstp[col], -src[cw]);
-            }
-        }
-    };
-    const int nt = (nf10 + 15) >> 4; // tile rows of the sum
-    __syncthreads(); // sE, sVar, sRhs and W of rounds 0 and 1 are visible
-    // ---- this wave's slices
-    const int rel = (int)(row_ptr[p0 + (lane * PB < np ? lane * PB : np)] - o0); // lane r: first observation of round r
-    // staging: planes k = 2 wv + j (j = 0, 1), observations sq = lane and lane + 64 of the round
-    const int k0s = 2 * wv;
-    const bool stager = k0s < 30;
-    double pre[4];
-    int sdst[2], nq_pre = 0;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        const int q = lane + 64 * h2, pl = q / nf, a = q - pl * nf; // uniform runs: landmark q / nf, slot q % nf
-        sdst[h2] = 3 * pl * LDW + 10 * a;
-    }
-    auto load_slice = [&](int r) { // global loads of round r into `pre` (left in flight)
-        const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
-        nq_pre = stager ? rb - ra : 0;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int q = lane + 64 * h2;
-            if (q < nq_pre) {
-                const WT* src = W + (int64_t)k0s * d.Os + o0 + ra + q;
-                pre[2 * h2] = src[0];
-                pre[2 * h2 + 1] = src[d.Os];
-                if (ragged) sdst[h2] = 3 * (obs_pt[o0 + ra + q] - (int)(p0 + r * PB)) * LDW + 10 * (int)obs_slot[o0 + ra + q];
-            }
-        }
-    };
-    auto stage_slice = [&](double* bw) { // `pre` -> W in LDS: plane k = 10 m + rr goes to row 3 pl + m, column 10 a + rr
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-            if (lane + 64 * h2 < nq_pre) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = k0s + j, m = k / 10, rr = k - 10 * m; // wave-uniform
-                    bw[sdst[h2] + m * LDW + rr] = pre[2 * h2 + j];
-                }
-            }
-    };
-    // Y = E^-1 W: this wave takes staged landmark ypl, columns 64 ych + lane, and keeps the rhs term W^T (E^-1 g) of them
-    const int ypl = __builtin_amdgcn_readfirstlane(wv >> 2), ych = __builtin_amdgcn_readfirstlane(wv & 3);
-    const int ycol = 64 * ych + lane;
-    const int ycc = ycol < nf10 ? ycol : LDW - 1; // a lane past the last column works on the padding column
-    double racc = 0;
-    uint32_t mask_pre = 0; // ragged runs: the frame slots this wave's landmark of the NEXT Y round sees
-    auto load_mask = [&](int r) { if (ragged && r * PB + ypl < np) mask_pre = pt_mask[p0 + r * PB + ypl]; };
-    auto y_slice = [&](int r, double* bw, double* by) { // Y of round r from its staged W
-        const int pb = r * PB;
-        const int nb = np - pb < PB ? np - pb : PB;
-        double* wp = bw + 3 * ypl * LDW + ycc;
-        double* yp = by + 3 * ypl * LDW + ycc;
-        if (ypl < nb) {
-            const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]); // rows are 96 B: 16-byte aligned
-            const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
-            double w0 = wp[0], w1 = wp[LDW], w2 = wp[2 * LDW];
-            if (ragged) { // a frame the landmark misses: zero blocks instead of the earlier round's stale W
-                const bool on = (mask_pre >> (ycol / 10)) & 1u;
-                w0 = on ? w0 : 0.0; w1 = on ? w1 : 0.0; w2 = on ? w2 : 0.0;
-                wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2;
-            }
-            yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
-            yp[LDW] = e23.y * w0 + e45.x * w1 + e45.y * w2;
-            yp[2 * LDW] = e67.x * w0 + e67.y * w1 + e89.x * w2;
-            const double rr = w0 * e89.y + w1 * eab.x + w2 * eab.y;
-            racc += ycol < nf10 ? rr : 0.0;
-        } else if (ych * 64 < LDW && ycol < LDW) {
-            // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
-            wp = bw + 3 * ypl * LDW + ycol;
-            yp = by + 3 * ypl * LDW + ycol;
-            wp[0] = wp[LDW] = wp[2 * LDW] = 0.0;
-            yp[0] = yp[LDW] = yp[2 * LDW] = 0.0;
-        }
-    };
-    // ---- this wave's tiles u = wv + NW s (row-major over (ti, tj <= ti)) of the nt x nt grid
-    const int n_tiles = nt * (nt + 1) / 2;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
-    const int lbase = lk * LDW + lr;
-    int ta[NS], tb[NS];
-    int ns = 0;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int u = wvu + NW * s;
-        const bool on = u < n_tiles;
-        const int uu = on ? u : 0;
-        int ti = (int)((sqrtf(8.0f * (float)uu + 1.0f) - 1.0f) * 0.5f);
-        while ((ti + 1) * (ti + 2) / 2 <= uu) ++ti;
-        while (ti * (ti + 1) / 2 > uu) --ti;
-        ta[s] = __builtin_amdgcn_readfirstlane(16 * ti);
-        tb[s] = __builtin_amdgcn_readfirstlane(16 * (uu - ti * (ti + 1) / 2));
-        ns += on ? 1 : 0;
-    }
-    ns = __builtin_amdgcn_readfirstlane(ns);
-    srk_double4 acc[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = (srk_double4){ 0, 0, 0, 0 };
-    // operands of half step hs = (K step hs / 2, tiles 3 (hs & 1) .. + 2); addresses re-formed per half step (see k_schur_mm)
-    auto load_ops = [&](double (&a)[3], double (&b)[3], const double* bw, const double* by, int hs) {
-        int lb = lbase;
-        asm volatile("" : "+v"(lb));
-        const int ko = (hs >> 1) * 4 * LDW, s0 = (hs & 1) * 3;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            a[s] = bw[ko + lb + ta[s0 + s]];
-            b[s] = by[ko + lb + tb[s0 + s]];
-        }
-    };
-    auto mac = [&](const double (&a)[3], const double (&b)[3], int hs) {
-        const int s0 = (hs & 1) * 3;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[s0 + s], 0, 0, 0);
-    };
-    load_mask(0);
-    y_slice(0, sBuf, sBuf + 3 * WB);
-    load_mask(1);
-    if (R > 2) load_slice(2);
-    lds_barrier(); // Y of round 0 is visible
-    int wi = 0; // W buffer of round r
-    for (int r = 0; r < R; ++r) {
-        const double* bw = sBuf + wi * WB;
-        const double* by = sBuf + (3 + (r & 1)) * WB;
-        const int w1 = wi == 2 ? 0 : wi + 1, w2 = w1 == 2 ? 0 : w1 + 1; // W buffers of rounds r + 1, r + 2
-        double a0[3], b0[3], a1[3], b1[3];
-        load_ops(a0, b0, bw, by, 0);
-        if (r + 2 < R) stage_slice(sBuf + w2 * WB);
-        load_ops(a1, b1, bw, by, 1); mac(a0, b0, 0);
-        if (r + 3 < R) load_slice(r + 3);
-        load_ops(a0, b0, bw, by, 2); mac(a1, b1, 1);
-        if (r + 1 < R) {
-            y_slice(r + 1, sBuf + w1 * WB, sBuf + (3 + ((r + 1) & 1)) * WB);
-            load_mask(r + 2);
-        }
-        load_ops(a1, b1, bw, by, 3); mac(a0, b0, 2);
-        load_ops(a0, b0, bw, by, 4); mac(a1, b1, 3);
-        load_ops(a1, b1, bw, by, 5); mac(a0, b0, 4);
-        mac(a1, b1, 5);
-        wi = w1;
-        lds_barrier(); // the products of round r; W of round r + 2 and Y of round r + 1 are visible
-    }
-    if (ycol < nf10) atomicAdd(&sRhs[ycol], racc);
-    // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg.  A tile just below the
-    // diagonal also supplies the mirror images the diagonal blocks it cuts need above the tile diagonal.
-#pragma nounroll
-    for (int t0 = 0; t0 < nt; t0 += TR) {
-        lds_barrier();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (s >= ns) continue;
-            const int ti = ta[s] >> 4, tj = tb[s] >> 4; // wave-uniform
-            if (ti >= t0 && ti < t0 + TR) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) sBuf[(ta[s] - 16 * t0 + lk + 4 * reg) * LDW + tb[s] + lr] = acc[s][reg];
-            }
-            if (ti == tj + 1 && tj >= t0 && tj < t0 + TR) {
-                const int Cc = tb[s] + lr, aC = Cc / 10;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int Rr = ta[s] + lk + 4 * reg;
-                    if (Rr < 10 * (aC + 1)) sBuf[(Cc - 16 * t0) * LDW + Rr] = acc[s][reg]; // same diagonal block
-                }
-            }
-        }
-        lds_barrier();
-        flush_stream(t0);
-    }
-    // rhs += sum F^T E^-1 g (the sRhs adds precede the flush's barriers; nf >= 1 means at least one pass)
-    if (tid < nf10 && sVar[tid] >= 0) atomicAdd(&rhs[sVar[tid]], sRhs[tid]);
-}
-
 // ------------------------------------------------------------------ K3l: long tracks as frame-block pairs (fp64 MFMA)
 // Landmarks seen by more than SRK_GRP_MAXNF frames (the demos' all-visible scenes: 36 and 60 frames; the MVF driver
 // calls the path with every track in every frame) used to go through the per-landmark kernel k_schur: one workgroup
@@ -2194,10 +1919,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
         else hipLaunchKernelGGL((KERNEL<__VA_ARGS__ double>), grid, block, 0, s, SRK_SCHUR_ARGS(W), nf_skip);       \
     } while (0)
     if (!no_ws && n_wide + n_mid < n_groups) { // runs over at most SRK_WS_NF frames: the MFMA kernel
-        static const bool env_mm1 = getenv("SRK_SCHUR_MM1") != nullptr; // development: the helper-wave kernel k_schur_mm
         if (env_valu) SRK_SCHUR_LAUNCH(k_schur_ws, block, double, );
-        else if (env_mm1) SRK_SCHUR_LAUNCH(k_schur_mm, dim3(SRK_MM_THREADS), );
-        else SRK_SCHUR_LAUNCH(k_schur_mm2, dim3(SRK_MM_THREADS), );
+        else SRK_SCHUR_LAUNCH(k_schur_mm, dim3(SRK_MM_THREADS), );
     }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread
         if (fp32_accumulate) SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 1, float, );
