@@ -202,6 +202,15 @@ def one_call_latency(sa):
         out["C1_dino_standin_warm_handle"] = timed(ba, 600.0, c1, crit)
     finally:
         ba.close()
+    # every track in every frame, at the size of the MVF flagfile's world (60 frames / 3321 points): the shape the demos'
+    # all-visible scenes have (tracks longer than 24 frames: k_schur_long)
+    av = sa.generate_scene(sa.SceneSpec(60, 81, 41, vis_window=0))
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        out["all_visible_60x3321_first_call"] = timed(ba, 600.0, av, crit, 5)
+        out["all_visible_60x3321_warm_handle"] = timed(ba, 600.0, av, crit, 5)
+    finally:
+        ba.close()
     # the multi-view-factorization caller itself: the drop-in of the reference demo with the reference flagfile's values
     # (60 frames / 3321 points; cpp_impl/flagfile-demo-multi-view-factorization.txt) hands BA the scene it has built so
     # far whenever its score exceeds 1e-3 (multi-view-factorization.cpp:379-394); wall time of those calls as the demo
@@ -434,8 +443,9 @@ def main():
                 "note": "one untimed step with the reduced camera system forced dense (--rcs dense gives the same)"}
         kernels["solve_panel_chain"] = {
             "bound": "latency", "ms": per_attempt["ms_solve"] - per_attempt["ms_solve_syrk"],
-            "note": "64-column panel kernels + backward substitution of the blocked Cholesky (+ gather / reduce / "
-                    "scatter of the nested-dissection levels): a dependency chain of pivots, bound by per-pivot "
+            "note": "outer-step kernels (k_step256: the four 64-column panels of a 256-column step as one launch whose "
+                    "workgroups hand tiles to one another) + backward substitution of the blocked Cholesky (+ gather / "
+                    "reduce of the nested-dissection levels): a dependency chain of pivots, bound by per-pivot "
                     "latency, not by HBM or MFMA throughput"}
         # The Schur sum is compute-bound (22 flop per algorithmic byte against a machine balance of ~10): price it against
         # the fp64 MFMA peak.  Useful flops: every landmark's lower block triangle, nf (nf + 1) / 2 blocks of 100 entries,
@@ -465,8 +475,8 @@ def main():
                          "achieved_GBs": skyline_bytes / (ms_sol * 1e-3) / 1e9 if ms_sol > 0 else 0.0,
                          "frac_of_hbm_peak": (skyline_bytes / (ms_sol * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_sol > 0 else 0.0},
             "ms_mfma_updates": ms_syrk, "ms_panel_chain": ms_sol - ms_syrk,
-            "note": "whole solve phase of one attempt (all levels of the nested dissection: gather, panels, updates, "
-                    "separator reduction, backward substitution, scatter); executed MFMA flops / phase time"}
+            "note": "whole solve phase of one attempt (all levels of the nested dissection: gather, fused outer steps, "
+                    "trailing updates, separator reduction, backward substitution); executed MFMA flops / phase time"}
         # dominant = the largest share of the step among the kernels / kernel classes (the solve phase is one candidate)
         shares = {"jacobian_kernel": per_it["ms_jacobian_kernel"], "schur_kernel_fp64": per_it["ms_schur"],
                   "solve_phase": per_it["ms_solve"], "backsub_phase": per_it["ms_backsub"],
