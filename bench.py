@@ -508,6 +508,9 @@ def main():
                        "exchange": exchange,
                        "points_per_rank": shard.N, "obs_per_rank": shard.O, "rcs_dim": 10 * M - 7,
                        "rcs_solver": args.rcs, "rcs_fill": rcs_fill, "rcs_chunks": rcs_chunks,
+                       "rcs_outer_step": "one launch per 256-column outer step, tiles handed between workgroups in the launch "
+                                         "(srk_ba_set_solver_fusion); solves repeated unfused after a hand-off timeout: "
+                                         f"{ba.solver_sync_timeouts()}",
                        "lm_attempts": "one attempt at a time (--sequential-attempts)" if args.sequential_attempts else
                                       "two attempt slots: the next damping factor runs beside the current one and is "
                                       "judged in the reference's order (srk_ba_set_speculation)"},

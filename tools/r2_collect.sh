@@ -11,4 +11,8 @@ for cfg in C1_dino_standin C2_200cam_20kpt C5_4kcam_1Mpt; do
   python bench.py --config $cfg --no-cpu-baseline --no-one-call --no-dense-probe > gpurun_out/r2/bench_$cfg.json 2> gpurun_out/r2/bench_$cfg.err
 done
 python bench.py --drop 0.1 --no-cpu-baseline --no-one-call --no-dense-probe > gpurun_out/r2/bench_C3_drop10.json 2> gpurun_out/r2/bench_C3_drop10.err
+python tools/dbg_long_tracks.py > gpurun_out/r2/long_tracks.txt 2>&1
+SRK_SCHUR_NO_LONG=1 python tools/dbg_long_tracks.py > gpurun_out/r2/long_tracks_per_landmark_kernel.txt 2>&1
+SRK_CHOL_FUSED=0 python bench.py --no-cpu-baseline --no-one-call --no-dense-probe > gpurun_out/r2/bench_C3_unfused_solve.json 2> gpurun_out/r2/bench_C3_unfused_solve.err
+bash tools/step_stamps.sh > gpurun_out/r2/step_stamps.txt 2>&1 || true
 echo collected
