@@ -528,6 +528,12 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        # the side measurements use handles of their own: the main handle goes first.  (HIP multiplexes a process's streams
+        # onto a few hardware queues, GPU_MAX_HW_QUEUES = 4 by default; with the main handle's two streams still open the
+        # probe handles' two attempt streams landed on ONE queue and their speculative pairs ran one after the other:
+        # config 1's one call took 18.6 instead of 12.3 ms.)
+        ba.close()
+        ba = None
         if world == 1 and not args.no_one_call:
             try:
                 out["one_call_ms"] = one_call_latency(sa)
@@ -540,7 +546,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    ba.close()
+    if ba is not None:
+        ba.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
