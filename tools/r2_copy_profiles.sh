@@ -1,0 +1,19 @@
+#!/bin/bash
+# copies what tools/r2_collect.sh left under gpurun_out/ into profiles/r2/ (run in the build container after the gpurun call)
+set -e
+cd "$(dirname "$0")/.."
+P=profiles/r2
+cp gpurun_out/prof_r2_final/bench.json $P/C3_bench_under_rocprof.json
+cp gpurun_out/prof_r2_final/runc/*_kernel_stats.csv $P/C3_kernel_stats.csv
+cp gpurun_out/prof_r2_final_seq/bench.json $P/C3_sequential_attempts_bench_under_rocprof.json
+cp gpurun_out/prof_r2_final_seq/runc/*_kernel_stats.csv $P/C3_sequential_attempts_kernel_stats.csv
+cp gpurun_out/r2/bench_C3.json $P/bench_C3_1kcam_100kpt.json
+for c in C1_dino_standin C2_200cam_20kpt C5_4kcam_1Mpt; do cp gpurun_out/r2/bench_$c.json $P/bench_$c.json; done
+cp gpurun_out/r2/bench_C3_drop10.json $P/bench_C3_drop10.json
+cp gpurun_out/r2/bench_C3_unfused_solve.json $P/bench_C3_unfused_solve.json
+cp gpurun_out/pmc_C3_1kcam_100kpt.json $P/pmc_C3_1kcam_100kpt.json
+cp gpurun_out/r2/pmc_C3.txt $P/pmc_C3_1kcam_100kpt.txt
+grep -v amdgpu.ids gpurun_out/r2/long_tracks.txt > $P/long_tracks.txt
+grep -v amdgpu.ids gpurun_out/r2/long_tracks_per_landmark_kernel.txt > $P/long_tracks_per_landmark_kernel.txt
+grep "^k_step256\|^role" gpurun_out/r2/step_stamps.txt > $P/step_stamps.txt || true
+ls -la $P
