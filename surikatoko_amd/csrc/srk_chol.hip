@@ -11,10 +11,13 @@
 //                  128x128 tile per workgroup, 64x64 per wave (4x4 accumulator tiles), K streamed through a
 //                  double-buffered LDS ring in chunks of 16.  K = 256 makes it 32 flop per HBM byte of C traffic
 //                  (a 64-deep update is HBM-bound at 8 flop/B).
-//   inner panel  = 64 columns (4 per outer panel): k_panel factorises the 64x64 diagonal tile (every workgroup
-//                  redundantly, in registers + LDS), solves its rows of the panel by substitution and folds the
-//                  forward substitution of the right-hand side in; k_upd64 applies the 64-deep update to the
-//                  remaining columns of the outer panel (MFMA as well).
+//   inner panel  = 64 columns (4 per outer panel).  Default: k_step256 runs the four inner panels of an outer step as
+//                  ONE launch whose workgroups hand factored tiles to one another (roles, hand-off protocol and the
+//                  deadlock argument: at the kernel).  The launch sequence it replaces stays (development switch,
+//                  repeat after a hand-off timeout, launches above 256 workgroups) and is bit-identical: k_panel
+//                  factorises the 64x64 diagonal tile (every workgroup redundantly, in registers + LDS), solves its
+//                  rows of the panel by substitution and folds the forward substitution of the right-hand side in;
+//                  k_upd64 applies the 64-deep update to the remaining columns of the outer panel (MFMA as well).
 // The per-outer-panel row limit `row_end` lets the caller skip the structurally zero part of a banded / skyline
 // system (the envelope of a Cholesky factor equals the envelope of the matrix); dense = ld for every panel.
 //
