@@ -940,6 +940,38 @@ def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_f
         gpu.set_solver_fusion(1)
 
 
+def test_fused_solve_hand_offs_stay_exact_beside_a_streaming_load():
+    """tools/stress_fused.py in small: the bench scene's reduced camera system solved 60 times with the fused outer
+    step while another stream keeps HBM busy (uneven load, consumer caches warm from the previous solve); every solution
+    must equal the unfused sequence's bit for bit and no hand-off may time out."""
+    import torch
+    spec = sa.CONFIGS["C3_1kcam_100kpt"]
+    sc = sa.generate_scene(spec)
+    h = sa.BundleAdjustmentKanatani(0)
+    try:
+        h.set_speculation(False)
+        assert h.upload(spec.f0, sc)
+        h.phase_derivatives()
+        h.phase_schur(1e-3)
+        h.set_solver_fusion(0)
+        assert h.phase_solve()
+        ref = h.buffer(B.BUF_CORRECTIONS)[3 * sc.N:].copy()
+        h.set_solver_fusion(1)
+        side = torch.cuda.Stream()
+        x = torch.empty(32 * 1024 * 1024, device="cuda", dtype=torch.float64)
+        y = torch.empty_like(x)
+        for it in range(60):
+            with torch.cuda.stream(side):
+                y.copy_(x)
+                x.add_(1.0)
+            assert h.phase_solve()
+            assert np.array_equal(h.buffer(B.BUF_CORRECTIONS)[3 * sc.N:], ref), it
+        torch.cuda.synchronize()
+        assert h.solver_sync_timeouts() == 0
+    finally:
+        h.close()
+
+
 def test_a_lost_hand_off_times_out_and_the_attempt_is_repeated_with_the_panel_sequence(gpu):
     """Every wait inside k_step256 is bounded.  Test hook: one launch's first diagonal workgroup does not publish its tile;
     its consumers give up, the solve reports bit 8, the LM loop repeats that attempt with the unfused kernels (and stays
