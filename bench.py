@@ -285,10 +285,37 @@ def main():
         # torch.distributed, nothing else does).  SRK_BENCH_EXCHANGE=torch keeps the Python callback of round 1
         # (torch.distributed.all_reduce with a host synchronisation on either side); the gloo rehearsal needs it.
         if backend == "nccl" and os.environ.get("SRK_BENCH_EXCHANGE", "rccl") == "rccl":
-            ident = [ba.rccl_unique_id() if rank == 0 else None]
+            # (if any rank cannot set the native communicator up, every rank takes the torch.distributed callback instead)
+            ok_native = 1
+            try:
+                ident = [ba.rccl_unique_id() if rank == 0 else None]
+            except Exception:  # noqa: BLE001
+                ident, ok_native = [None], 0
             dist.broadcast_object_list(ident, src=0)
-            ba.rccl_init(ident[0], rank, world)
-            exchange = "native RCCL all-reduce on the library's streams"
+            if ident[0] is None:
+                ok_native = 0
+            if ok_native:
+                try:
+                    ba.rccl_init(ident[0], rank, world)
+                except Exception:  # noqa: BLE001
+                    ok_native = 0
+            flag = torch.tensor([ok_native], device=f"cuda:{local_rank}", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = "native RCCL all-reduce on the library's streams"
+            else:
+                ba.close()
+                ba = sa.BundleAdjustmentKanatani(local_rank)
+                ba.set_profile(0)
+                if args.schur_fp32:
+                    ba.set_schur_precision(True)
+                if args.store_f32:
+                    ba.set_storage_precision(True)
+                if args.sequential_attempts:
+                    ba.set_speculation(False)
+                from surikatoko_amd.dist import make_allreduce_hook
+                ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
+                exchange = "torch.distributed all_reduce callback (nccl; the native communicator could not be set up)"
         else:
             from surikatoko_amd.dist import make_allreduce_hook
             ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
