@@ -297,6 +297,12 @@ def main():
             if ok_native:
                 try:
                     ba.rccl_init(ident[0], rank, world)
+                    # the second attempt slot's own communicator: the speculative attempt pairs stay on (SRK_BENCH_PAIRS=0:
+                    # one attempt at a time, as every N > 1 run before round 2)
+                    if os.environ.get("SRK_BENCH_PAIRS", "1") != "0" and not args.sequential_attempts:
+                        ident2 = [ba.rccl_unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(ident2, src=0)
+                        ba.rccl_init_second(ident2[0])
                 except Exception:  # noqa: BLE001
                     ok_native = 0
             flag = torch.tensor([ok_native], device=f"cuda:{local_rank}", dtype=torch.int32)

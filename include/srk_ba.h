@@ -106,10 +106,15 @@ int srk_ba_set_allreduce(srk_ba*, srk_allreduce_fn fn, void* ctx, int rank, int 
  * per GPU, one handle each).  librccl.so is opened on first use.
  *   srk_ba_rccl_get_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by any means;
  *   srk_ba_rccl_init:          every rank creates the communicator on its handle's device (collective call);
+ *   srk_ba_rccl_init_second:   (optional, collective, after srk_ba_rccl_init, with a second unique id) a communicator of
+ *                              its own for the second attempt slot: with it the LM loop keeps its speculative attempt
+ *                              pairs with several ranks (each slot's all-reduces on its own stream and communicator);
+ *                              without it one attempt runs at a time;
  *   srk_ba_rccl_set_comm:      use a communicator (ncclComm_t) the caller owns instead; NULL detaches.
  * Either replaces a callback set with srk_ba_set_allreduce.  Call before srk_ba_upload_scene. */
 int srk_ba_rccl_get_unique_id(void* id128 /* out: 128 bytes */);
 int srk_ba_rccl_init(srk_ba*, const void* id128, int rank, int world_size);
+int srk_ba_rccl_init_second(srk_ba*, const void* id128);
 int srk_ba_rccl_set_comm(srk_ba*, void* nccl_comm, int rank, int world_size);
 
 /* ---- the reference API, one call ---- */

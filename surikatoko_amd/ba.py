@@ -355,6 +355,12 @@ class BundleAdjustmentKanatani:
         self._raise(self._lib.srk_ba_rccl_init(C.c_void_p(self._h), buf, C.c_int(int(rank)), C.c_int(int(world))))
         self._hook = None
 
+    def rccl_init_second(self, unique_id):
+        """Collective, after rccl_init: the second attempt slot's own communicator (keeps the attempt pairs with several ranks)."""
+        assert len(unique_id) == 128
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._raise(self._lib.srk_ba_rccl_init_second(C.c_void_p(self._h), buf))
+
     def phase_error(self):
         e, seen = C.c_double(0), C.c_int64(0)
         self._raise(self._lib.srk_ba_phase_error(C.c_void_p(self._h), C.byref(e), C.byref(seen)))

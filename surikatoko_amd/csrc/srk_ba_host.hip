@@ -107,6 +107,12 @@ struct srk_ba {
     // no host round trip, no Python.  comm_owned: created by srk_ba_rccl_init (destroyed with the handle).
     ncclComm_t comm = nullptr;
     bool comm_owned = false;
+    // a second communicator for the second attempt slot (srk_ba_rccl_init_second): with it the speculative pairs stay on
+    // with several ranks -- each slot's all-reduces run on its own stream AND its own communicator, so the two slots'
+    // collectives never share a communicator's queue.  Without it (or with the all-reduce callback, which blocks the
+    // host) pairs stay on as well when spec_multi allows: the callback serialises the exchanges on the host.
+    ncclComm_t comm2 = nullptr;
+    bool spec_multi = true; // SRK_MULTI_SPECULATION=0: one attempt at a time with several ranks
     int64_t seen_global = -1; // observation count over all ranks of the uploaded scene (-1 = not yet exchanged)
 
     // timing
@@ -226,6 +232,7 @@ srk_ba* srk_ba_create(int device_id)
     }
     h->main_stream = h->stream;
     if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = e[0] != '0'; // development: the unfused launch sequence
+    if (const char* e = getenv("SRK_MULTI_SPECULATION")) h->spec_multi = e[0] != '0';
     h->att[0].stream = h->stream;
     h->att[0].trial = 1;
     h->att[1].trial = 2;
@@ -329,6 +336,8 @@ int srk_ba_rccl_get_unique_id(void* id128)
 static int rccl_attach(srk_ba* h, ncclComm_t comm, bool owned, int rank, int world_size)
 {
     if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
+    if (h->comm2) rccl().CommDestroy(h->comm2);
+    h->comm2 = nullptr;
     h->comm = comm;
     h->comm_owned = owned;
     h->allreduce = nullptr;
@@ -349,6 +358,21 @@ int srk_ba_rccl_init(srk_ba* h, const void* id128, int rank, int world_size)
     ncclResult_t r = rccl().CommInitRank(&comm, world_size, id, rank);
     if (r != ncclSuccess) { h->last_error = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r); return SRK_E_DEVICE; }
     return rccl_attach(h, comm, true, rank, world_size);
+}
+// collective, after srk_ba_rccl_init: a second communicator (its own ncclUniqueId) for the second attempt slot
+int srk_ba_rccl_init_second(srk_ba* h, const void* id128)
+{
+    if (!h || !id128) return SRK_E_ARGS;
+    if (!h->comm || !rccl().ok) { h->last_error = "srk_ba_rccl_init_second: srk_ba_rccl_init comes first"; return SRK_E_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = rccl().CommInitRank(&comm, h->world, id, h->rank);
+    if (r != ncclSuccess) { h->last_error = std::string("ncclCommInitRank (second): ") + rccl().GetErrorString(r); return SRK_E_DEVICE; }
+    if (h->comm2) rccl().CommDestroy(h->comm2);
+    h->comm2 = comm;
+    return SRK_OK;
 }
 int srk_ba_rccl_set_comm(srk_ba* h, void* nccl_comm, int rank, int world_size)
 {
@@ -1142,7 +1166,8 @@ extern "C" int srk_ba_download_scene(srk_ba* h, double* pts, double* cam_R, doub
 static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
 {
     if (h->comm) { // RCCL on this attempt's stream: ordered behind the kernels that filled the buffer, nothing waits on the host
-        ncclResult_t r = rccl().AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream);
+        ncclComm_t comm = (h->A == &h->att[1] && h->comm2) ? h->comm2 : h->comm; // the second slot's own communicator
+        ncclResult_t r = rccl().AllReduce(dev_ptr, dev_ptr, (size_t)count, ncclDouble, ncclSum, comm, h->stream);
         if (r != ncclSuccess) {
             h->last_error = std::string("ncclAllReduce: ") + rccl().GetErrorString(r);
             return SRK_E_DEVICE;
@@ -1518,7 +1543,11 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         auto judge_attempt = [&](int sl) -> int {
             if (hipStreamSynchronize(h->att[sl].stream) != hipSuccess) return SRK_E_DEVICE;
             const double* hb = h->att[sl].host_back;
-            if (((int)hb[1] & 8) != 0) {
+            // (several ranks: the status words are SUMMED over the ranks, so bit 8 cannot be told from two ranks' bit 4; any
+            // non-zero status of a fused solve is then taken for a possible timeout -- every rank sees the same sum and
+            // repeats, a genuine failure shows again without the fused kernels)
+            const bool multi_rank = h->allreduce || h->comm;
+            if (multi_rank ? ((int)hb[1] != 0 && h->att[sl].sync.fused) : (((int)hb[1] & 8) != 0)) {
                 // an in-launch hand-off of the fused solve timed out (srk_chol.hip: k_step256; its spins are bounded): the
                 // numbers of this attempt are void.  From now on the unfused launch sequence (bit-identical arithmetic);
                 // this attempt is repeated with the factor it stands for, which is `hessian_factor` at this point.
@@ -1566,10 +1595,12 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             if (r2 == SRK_OK) r2 = enqueue_rest(sl, c);
             return r2;
         };
-        // several ranks: one attempt at a time.  (Every rank takes the same decisions, so the two slots' exchanges would be
-        // issued in the same order everywhere -- but that path has never run over RCCL on hardware: it stays off until
-        // an N > 1 run has covered it.)
-        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0 && !h->allreduce && !h->comm;
+        // several ranks: every rank takes the same decisions, so the two slots' exchanges are issued in the same order
+        // everywhere; the native path wants the second slot's own communicator (srk_ba_rccl_init_second), the callback
+        // serialises the exchanges on the host
+        const bool multi = h->allreduce || h->comm;
+        const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0 &&
+                                   (!multi || (h->spec_multi && (h->allreduce || h->comm2)));
         bool spec_in_flight = false;
         int round = 0;
         const int64_t attempts_before = rep->attempts;
