@@ -767,6 +767,33 @@ def test_native_rccl_exchange_world_size_1(orc):
         ba.close()
 
 
+def test_native_rccl_two_communicators_keep_the_attempt_pairs_world_size_1(orc):
+    """srk_ba_rccl_init_second: the second attempt slot's own communicator, so that the speculative attempt pairs stay on
+    with the native exchange -- two communicators on one device, all-reduces of both slots in flight on two streams, at
+    world size 1 (all one GPU can run).  Same accept / reject sequence and numbers as the oracle's sequential loop."""
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        ba.rccl_init(ba.rccl_unique_id(), 0, 1)
+        ba.rccl_init_second(ba.rccl_unique_id())
+        so = _orc_scene(orc, sc)
+        rc_o, rep_o = orc.compute_inplace(spec.f0, so, 1e-7, 1e6, 40)
+        crit = sa.BundleAdjustmentKanataniTermCriteria()
+        crit.AllowedReprojErrRelativeChange(1e-7)
+        crit.MaxHessianFactor(1e6)
+        sg = sc.copy()
+        ok = ba.ComputeInplace(spec.f0, sg, crit, 40)
+        rep = ba.report
+        assert ok == (rc_o == 0) and sa.status_string(rep.status) == orc.status_string(rep_o.status)
+        assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+        assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+        assert np.abs(sg.points - so.points).max() < 1e-6
+        assert ba.solver_sync_timeouts() == 0
+    finally:
+        ba.close()
+
+
 def test_allreduce_hook_with_device_pointers(orc, gpu):
     """The RCCL path end to end at world size 1: the library packs the skyline, calls the torch.distributed hook with
     DEVICE pointers (zero-copy __cuda_array_interface__ views) and must give the same iterations as without it."""
