@@ -4,9 +4,9 @@ set -e
 cd "$(dirname "$0")/.."
 P=profiles/r2
 cp gpurun_out/prof_r2_final/bench.json $P/C3_bench_under_rocprof.json
-cp gpurun_out/prof_r2_final/runc/*_kernel_stats.csv $P/C3_kernel_stats.csv
+cp "$(ls -t gpurun_out/prof_r2_final/runc/*_kernel_stats.csv | head -1)" $P/C3_kernel_stats.csv
 cp gpurun_out/prof_r2_final_seq/bench.json $P/C3_sequential_attempts_bench_under_rocprof.json
-cp gpurun_out/prof_r2_final_seq/runc/*_kernel_stats.csv $P/C3_sequential_attempts_kernel_stats.csv
+cp "$(ls -t gpurun_out/prof_r2_final_seq/runc/*_kernel_stats.csv | head -1)" $P/C3_sequential_attempts_kernel_stats.csv
 cp gpurun_out/r2/bench_C3.json $P/bench_C3_1kcam_100kpt.json
 for c in C1_dino_standin C2_200cam_20kpt C5_4kcam_1Mpt; do cp gpurun_out/r2/bench_$c.json $P/bench_$c.json; done
 cp gpurun_out/r2/bench_C3_drop10.json $P/bench_C3_drop10.json
