@@ -76,7 +76,7 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
 // tracks longer than SRK_GRP_MAXNF_HOST frames: runs of <= SRK_LONG_PTS_HOST landmarks over a frame set of
 // <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur
 #define SRK_LONG_PTS_HOST 128
-#define SRK_LONG_MAXNF_HOST 128
+#define SRK_LONG_MAXNF_HOST 256
 #define SRK_LONG_FB_HOST 8
 void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const double* W, const double* Vg, double* S, double* rhs,
                            const int32_t* item /* [n_items][4]: run, row block, column block (<= row block), 0 */,

@@ -295,14 +295,15 @@ def test_phases_on_ragged_tracks(orc, gpu, name, c):
 
 LONG_TRACKS = {
     # k_schur_long: tracks over more than 24 frames, summed per pair of 8-frame blocks as fp64 MFMA products.  Frame sets
-    # that are / are not a whole number of blocks, the shortest long track, the longest a run holds, a track beyond that
+    # that are / are not a whole number of blocks, the shortest long track, the longest a run holds (256 frames), a track beyond that
     # (per-landmark kernel), runs that are not a multiple of eight landmarks, several runs, ragged unions
     "demo_circle_grid_36": (sa.SceneSpec(n_frames=36, grid_nx=9, grid_ny=9, vis_window=0), 0.0),     # the demo's 81 x 36, all visible
     "mvf_60_two_runs": (sa.SceneSpec(n_frames=60, grid_nx=15, grid_ny=13, vis_window=0), 0.0),       # 195 landmarks: runs of 128 + 67
     "nf25": (sa.SceneSpec(n_frames=27, grid_nx=7, grid_ny=5, vis_window=25), 0.0),
     "nf64_whole_blocks": (sa.SceneSpec(n_frames=64, grid_nx=5, grid_ny=4, vis_window=0), 0.0),
-    "nf128_full_run": (sa.SceneSpec(n_frames=128, grid_nx=4, grid_ny=3, vis_window=0), 0.0),
-    "nf130_beyond_a_run": (sa.SceneSpec(n_frames=130, grid_nx=3, grid_ny=3, vis_window=0), 0.0),
+    "nf128_many_pairs": (sa.SceneSpec(n_frames=128, grid_nx=4, grid_ny=3, vis_window=0), 0.0),
+    "nf256_full_run": (sa.SceneSpec(n_frames=256, grid_nx=3, grid_ny=3, vis_window=0), 0.0),
+    "nf260_beyond_a_run": (sa.SceneSpec(n_frames=260, grid_nx=3, grid_ny=2, vis_window=0), 0.0),
     "ragged_40": (sa.SceneSpec(n_frames=70, grid_nx=14, grid_ny=12, vis_window=40, noise_uv_pix=0.3), 0.25),
     "mixed_short_and_long": (sa.SceneSpec(n_frames=48, grid_nx=12, grid_ny=10, vis_window=30), 0.35),  # tracks of 12..30 frames
 }

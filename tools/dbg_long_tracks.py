@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import surikatoko_amd as sa, torch
 for name, spec in (("circle_grid 36 x 81", sa.SceneSpec(36, 9, 9, vis_window=0)),
                    ("mvf flagfile 60 x 3321", sa.SceneSpec(60, 81, 41, vis_window=0)),
-                   ("window 40, 200 x 20000", sa.SceneSpec(200, 200, 100, vis_window=40))):
+                   ("window 40, 200 x 20000", sa.SceneSpec(200, 200, 100, vis_window=40)),
+                   ("all visible, 200 x 5000 (dense variant of config 2, a quarter of its points)", sa.SceneSpec(200, 100, 50, vis_window=0))):
     sc = sa.generate_scene(spec)
     ba = sa.BundleAdjustmentKanatani(0)
     ba.set_profile(1)
