@@ -10,6 +10,7 @@
 // run of landmarks) these kernels are HBM-bound streaming passes over the observation arrays: every global access is lane-contiguous (SoA blocks), per-landmark sums are wavefront
 // segmented reductions, per-frame sums are register accumulators + wavefront reductions + one atomic per block.
 #include "srk_dev.hpp"
+#include <type_traits>
 
 #define WAVE 64
 
@@ -1367,8 +1368,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define SRK_MM_SLOTS 8  // tiles per multiplying wave
 #define SRK_MM_LDW 208  // row stride of the round buffers (doubles): 13 tiles of 16 columns
 typedef double srk_double4 __attribute__((ext_vector_type(4)));
-// the K = 4 steps of one round for a wave with NS tiles: operands of all tiles first, then the MFMAs (branch-free)
-template <int NS>
+// the K = 4 steps of one round for a wave with NS tiles: operands of all tiles first, then the MFMAs (branch-free).
+// P0 / P1: operand pattern of the wave's tiles 0 .. 3 / 4 .. 7 (the two half steps of a K step):
+//   0   every tile with its own A (row) and B (column) operand: 8 LDS reads per 4 MFMAs;
+//   4   the four tiles lie in ONE tile row: one A serves them (5 reads);
+//   13, 22, 31   the first 1 / 2 / 3 tiles lie in one tile row, the others in a second one: two A operands (6 reads).
+// tools/ubench/mfma64_lds.hip: an LDS-fed fp64 MFMA stream issues an MFMA every ~88 cycles with one operand pair per
+// MFMA and every ~73 when an operand serves two -- the reads, not their latency, are what the stream waits for.
+template <int NS, int P0, int P1>
 __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, const double* by,
                                                const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int lbase)
 {
@@ -1377,31 +1384,41 @@ __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS],
     // offset) are formed again at every half step -- opaque to the compiler, which would otherwise keep all 16 of them
     // in VGPRs -- so that a second operand set fits the 128 registers: the next half step's LDS reads are in flight
     // while this one's four MFMAs issue.
-    auto load = [&](double (&a)[4], double (&b)[4], int hs) {
+    auto load = [&](double (&a)[4], double (&b)[4], int hs, auto pc) {
+        constexpr int P = decltype(pc)::value;
         int lb = lbase;
         asm volatile("" : "+v"(lb));
         const int ko = (hs >> 1) * 4 * SRK_MM_LDW, s0 = (hs & 1) * 4;
+        if constexpr (P == 0) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a[s] = bw[ko + lb + ta[s0 + s]];
-            b[s] = by[ko + lb + tb[s0 + s]];
+            for (int s = 0; s < 4; ++s) a[s] = bw[ko + lb + ta[s0 + s]];
+        } else {
+            a[0] = bw[ko + lb + ta[s0]];
+            if constexpr (P != 4) a[3] = bw[ko + lb + ta[s0 + 3]];
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = by[ko + lb + tb[s0 + s]];
     };
-    auto mac = [&](const double (&a)[4], const double (&b)[4], int hs) {
+    auto mac = [&](const double (&a)[4], const double (&b)[4], int hs, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int NF = P == 0 ? 0 : (P == 4 ? 4 : P / 10); // tiles of the half step in its first tile row
         const int s0 = (hs & 1) * 4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[s0 + s], 0, 0, 0);
+        for (int s = 0; s < 4; ++s)
+            acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(P == 0 ? a[s] : (s < NF ? a[0] : a[3]), b[s], acc[s0 + s], 0, 0, 0);
     };
+    using C0 = std::integral_constant<int, P0>;
+    using C1 = std::integral_constant<int, P1>;
     // always the three K steps of a full round: in a short last round the k rows of the missing landmarks are zeros
     // (y_round), and one code path keeps the accumulators in place
     double a0[4], b0[4], a1[4], b1[4];
-    load(a0, b0, 0);
-    load(a1, b1, 1); mac(a0, b0, 0);
-    load(a0, b0, 2); mac(a1, b1, 1);
-    load(a1, b1, 3); mac(a0, b0, 2);
-    load(a0, b0, 4); mac(a1, b1, 3);
-    load(a1, b1, 5); mac(a0, b0, 4);
-    mac(a1, b1, 5);
+    load(a0, b0, 0, C0{});
+    load(a1, b1, 1, C1{}); mac(a0, b0, 0, C0{});
+    load(a0, b0, 2, C0{}); mac(a1, b1, 1, C1{});
+    load(a1, b1, 3, C1{}); mac(a0, b0, 2, C0{});
+    load(a0, b0, 4, C0{}); mac(a1, b1, 3, C1{});
+    load(a1, b1, 5, C1{}); mac(a0, b0, 4, C0{});
+    mac(a1, b1, 5, C1{});
 }
 template <typename WT>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
@@ -1652,9 +1669,12 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int lbase = lk * LDW + lr;
         int ta[SRK_MM_SLOTS], tb[SRK_MM_SLOTS];
         int ns = 0; // this wave's tiles
+        // The full-size grid (nt = 13: 20 frames, the bench scenes) is dealt out as RUNS of eight consecutive tiles: four
+        // consecutive tiles span at most two tile rows, so one or two A operands serve a half step (schur_mm_steps).
+        const bool runs = nt == 13;
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
-            const int u = wvu + SRK_MM_CW * s;
+            const int u = runs ? SRK_MM_SLOTS * wvu + s : wvu + SRK_MM_CW * s;
             const bool on = u < n_tiles;
             const int uu = on ? u : 0;
             int ti = (int)((sqrtf(8.0f * (float)uu + 1.0f) - 1.0f) * 0.5f);
@@ -1673,20 +1693,50 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #ifdef SRK_MM_STAMPS
         tacc = wall_clock64();
 #endif
-        int wi = 0; // W buffer of round r
-        for (int r = 0; r < R; ++r) {
-            const double* bw = sBuf + wi * WB;
-            const double* by = sBuf + (3 + (r & 1)) * WB;
-            wi = wi == 2 ? 0 : wi + 1;
+        // operand pattern of each half step, from the tile rows themselves (an idle slot multiplies tile (0, 0): any
+        // pattern its row happens to match is fine, its sum is never flushed)
+        auto pattern = [&](int s0) {
+            const int r0 = ta[s0], r1 = ta[s0 + 1], r2 = ta[s0 + 2], r3 = ta[s0 + 3];
+            if (!runs) return 0;
+            if (r0 == r1 && r1 == r2 && r2 == r3) return 4;
+            if (r0 == r1 && r1 == r2) return 31;
+            if (r0 == r1 && r2 == r3) return 22;
+            if (r1 == r2 && r2 == r3) return 13;
+            return 0;
+        };
+        const int pat = __builtin_amdgcn_readfirstlane(100 * pattern(0) + pattern(4));
+        auto rounds = [&](auto p0, auto p1) {
+            int wi = 0; // W buffer of round r
+            for (int r = 0; r < R; ++r) {
+                const double* bw = sBuf + wi * WB;
+                const double* by = sBuf + (3 + (r & 1)) * WB;
+                wi = wi == 2 ? 0 : wi + 1;
 #ifdef SRK_SCH_NOACC
-            if (d.N < 0)
+                if (d.N < 0)
 #endif
-            schur_mm_steps<SRK_MM_SLOTS>(acc, bw, by, ta, tb, lbase); // idle slots multiply tile (0, 0)
-            MM_ACC(0, 6, tacc);
+                schur_mm_steps<SRK_MM_SLOTS, decltype(p0)::value, decltype(p1)::value>(acc, bw, by, ta, tb, lbase); // idle slots multiply tile (0, 0)
+                MM_ACC(0, 6, tacc);
 #ifndef SRK_MM_NO_ROUND_BARRIER
-            lds_barrier();
+                lds_barrier();
 #endif
-            MM_ACC(0, 7, tacc);
+                MM_ACC(0, 7, tacc);
+            }
+        };
+        {
+            using std::integral_constant;
+#define SRK_MM_CASE(A, B) case 100 * A + B: rounds(integral_constant<int, A>{}, integral_constant<int, B>{}); break
+            switch (pat) { // the patterns of the nt = 13 runs; anything else takes the general form
+            SRK_MM_CASE(4, 4);
+            SRK_MM_CASE(4, 13);
+            SRK_MM_CASE(4, 22);
+            SRK_MM_CASE(4, 31);
+            SRK_MM_CASE(22, 4);
+            SRK_MM_CASE(22, 31);
+            SRK_MM_CASE(0, 22);
+            SRK_MM_CASE(31, 4);
+            default: rounds(integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+            }
+#undef SRK_MM_CASE
         }
         MM_STAMP(3);
         // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg.  A tile just below the
