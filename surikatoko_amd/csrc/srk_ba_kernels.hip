@@ -1671,7 +1671,8 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         int ns = 0; // this wave's tiles
         // The full-size grid (nt = 13: 20 frames, the bench scenes) is dealt out as RUNS of eight consecutive tiles: four
         // consecutive tiles span at most two tile rows, so one or two A operands serve a half step (schur_mm_steps).
-        const bool runs = nt == 13;
+        // (uniform runs only: on ragged runs -- the helpers also mask and rewrite W there -- it made the sum 9 % slower)
+        const bool runs = nt == 13 && !ragged;
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
             const int u = runs ? SRK_MM_SLOTS * wvu + s : wvu + SRK_MM_CW * s;
