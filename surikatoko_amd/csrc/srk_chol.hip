@@ -548,6 +548,9 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
 #define ST_G(t, d) (8 + (t) * ((t) - 1) / 2 + (d))  // X_td published, 1 <= t <= 3, d < t
 #define ST_WORDS 16
 #define ST_SPIN_MAX (1 << 17)
+#ifndef ST_POLL_SLEEP
+#define ST_POLL_SLEEP 2
+#endif
 typedef unsigned int __attribute__((address_space(1))) gu32_t;
 __device__ __forceinline__ void st_store(double* p, double v) // write-through store (global_store_dwordx2 sc1)
 {
@@ -588,7 +591,7 @@ __device__ __forceinline__ void st_wait(unsigned* fl, unsigned mask, unsigned ep
                 atomicOr(info, 8);
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(ST_POLL_SLEEP);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
