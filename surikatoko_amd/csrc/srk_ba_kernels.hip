@@ -1420,6 +1420,45 @@ __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS],
     load(a1, b1, 5, C1{}); mac(a0, b0, 4, C0{});
     mac(a1, b1, 5, C1{});
 }
+// the same for a wave whose eight tiles are a 2 x 4 BLOCK of the tile grid (tiles 0 .. 3: row ta[0], columns tb[0 .. 3];
+// tiles 4 .. 7: row ta[4], the same columns): two A and four B operands serve the eight MFMAs of a K step -- 6 LDS reads
+// instead of 16 -- and the operand sets are per K step (the next one's reads in flight under eight MFMAs)
+__device__ __forceinline__ void schur_mm_steps_blk(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, const double* by,
+                                                   const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int lbase)
+{
+    struct Ops { double alo, ahi, b[4]; };
+    auto load = [&](Ops& o, int ks) {
+        int lb = lbase;
+        asm volatile("" : "+v"(lb));
+        const int ko = ks * 4 * SRK_MM_LDW;
+        o.alo = bw[ko + lb + ta[0]];
+        o.ahi = bw[ko + lb + ta[4]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.b[j] = by[ko + lb + tb[j]];
+    };
+    auto mac = [&](const Ops& o) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo, o.b[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi, o.b[j], acc[4 + j], 0, 0, 0);
+    };
+    Ops o0, o1;
+    load(o0, 0);
+    load(o1, 1); mac(o0);
+    load(o0, 2); mac(o1);
+    mac(o0);
+}
+// nt = 13 (20 frames): the 91 tiles of the lower triangle over the 12 multiplying waves.  Nine waves take a 2 x 4 block
+// (two tile rows, four tile columns; where the block reaches over the diagonal that tile is computed and not flushed),
+// wave 9 the first eight tiles of the last row, waves 10 and 11 what is left.  {ti, tj} per slot, ti < 0: idle slot.
+__device__ const signed char srk_mm_tiles13[SRK_MM_CW][SRK_MM_SLOTS][2] = {
+#define SRK_BLK(r, c) { { r, c }, { r, c + 1 }, { r, c + 2 }, { r, c + 3 }, { r + 1, c }, { r + 1, c + 1 }, { r + 1, c + 2 }, { r + 1, c + 3 } }
+    SRK_BLK(10, 0), SRK_BLK(10, 4), SRK_BLK(10, 8), SRK_BLK(8, 0), SRK_BLK(8, 4), SRK_BLK(6, 0), SRK_BLK(6, 4), SRK_BLK(4, 0), SRK_BLK(2, 0),
+#undef SRK_BLK
+    { { 12, 0 }, { 12, 1 }, { 12, 2 }, { 12, 3 }, { 12, 4 }, { 12, 5 }, { 12, 6 }, { 12, 7 } },
+    { { 12, 8 }, { 12, 9 }, { 12, 10 }, { 12, 11 }, { 12, 12 }, { 8, 8 }, { 9, 8 }, { 9, 9 } },
+    { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { -1, 0 }, { -1, 0 } },
+};
 template <typename WT>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
@@ -1432,7 +1471,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     constexpr int KR = 3 * PB;                 // k rows of a round
     constexpr int LDW = SRK_MM_LDW;            // row stride (doubles)
     constexpr int WB = KR * LDW;               // one buffer: W or Y of a round
-    constexpr int CAP = 5 * WB;                // W0 | W1 | W2 | Y0 | Y1; the flush uses all of it
+    constexpr int CAP = 6 * WB;                // W0 | W1 | W2 | Y0 | Y1 | Y2 (ragged runs use Y0, Y1); the flush uses all of it
     constexpr int QMAX = PB * SRK_WS_NF;       // observations of a round
     constexpr int NH = SRK_MM_THREADS - 64 * SRK_MM_CW; // helper lanes
     constexpr int NW = SRK_MM_THREADS / 64;
@@ -1619,15 +1658,98 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (nb < PB)
                 for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = by[3 * nb * LDW + t] = 0;
         };
+        // Uniform runs (every landmark sees the run's whole frame set), rounds >= 2: W and Y of a round are staged TOGETHER,
+        // straight from the registers the global loads landed in.  In-kernel stamps of the two-pass form below (stage W,
+        // then read it back and form Y a round later): the helpers -- which only issue while their SIMD's multiplying
+        // waves are stalled -- spent 2.4 us a round in the Y pass, and the multiplying waves stood at the round barrier.
+        // Lane h = QMAX i0 + q takes observation q of the round and the frame variables i = i0, i0 + 3, i0 + 6 (, 9): all
+        // three point coordinates of a column are its own loads, so y = E^-1 w needs no LDS read-back, the landmark's E
+        // stays in registers for the lane's four columns, and W, Y leave as plain LDS writes.  Y is triple-buffered like W.
+        constexpr int NBT = 4; // column batches of a lane
+        const int q2 = h % QMAX, i02 = h / QMAX;
+        const int pl2 = q2 / nf, a2 = q2 - pl2 * nf;
+        const int dst2 = 3 * pl2 * LDW + 10 * a2;
+        double pre2[NBT][3], racc2[NBT];
+#pragma unroll
+        for (int b = 0; b < NBT; ++b) racc2[b] = 0;
+        int nq2 = 0;
+        auto load_round2 = [&](int r) {
+            const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
+            nq2 = i02 < 3 ? rb - ra : 0;
+            if (q2 < nq2) {
+                // plane base (wave-uniform: scalar registers) + one 32-bit lane offset: no 64-bit address arithmetic per load
+                const unsigned voff = (unsigned)(o0 + ra + q2) + (unsigned)i02 * (unsigned)d.Os;
+#pragma unroll
+                for (int b = 0; b < NBT; ++b) {
+                    if (i02 + 3 * b < 10) {
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            const WT* sb = W + (int64_t)(10 * m + 3 * b) * d.Os;
+                            pre2[b][m] = sb[voff];
+                        }
+                    }
+                }
+            }
+        };
+        auto stage_round2 = [&](int r, double* bw, double* by) {
+            const int pb = r * PB;
+            const int nb = np - pb < PB ? np - pb : PB;
+            if (q2 < nq2) {
+                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + pl2]);
+                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
+#pragma unroll
+                for (int b = 0; b < NBT; ++b) {
+                    const int i = i02 + 3 * b;
+                    if (i < 10) {
+                        const double w0 = pre2[b][0], w1 = pre2[b][1], w2 = pre2[b][2];
+                        double* wp = bw + dst2 + i;
+                        double* yp = by + dst2 + i;
+                        wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2;
+                        yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
+                        yp[LDW] = e23.y * w0 + e45.x * w1 + e45.y * w2;
+                        yp[2 * LDW] = e67.x * w0 + e67.y * w1 + e89.x * w2;
+                        racc2[b] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
+                    }
+                }
+            }
+            // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
+            if (nb < PB)
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = by[3 * nb * LDW + t] = 0;
+        };
         load_mask(0);
         y_round(0, sBuf, sBuf + 3 * WB);
         load_mask(1);
-        if (R > 2) load_round(2);
+        if (!ragged) {
+            if (R > 1) y_round(1, sBuf + WB, sBuf + 4 * WB);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) { // the two-pass rounds' share of the rhs: out of the registers before the loop
+                if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
+                racc[i] = 0;
+            }
+            if (R > 2) load_round2(2);
+        } else if (R > 2) load_round(2);
         lds_barrier(); // Y of round 0 is visible
 #ifdef SRK_MM_STAMPS
         tacc = wall_clock64();
 #endif
         int wi = 2; // W buffer of round r + 2
+        if (!ragged) {
+            for (int r = 0; r < R; ++r) {
+                if (r + 2 < R) stage_round2(r + 2, sBuf + wi * WB, sBuf + (3 + wi) * WB);
+#ifdef SRK_MM_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                MM_ACC(64 * SRK_MM_CW, 10, tacc);
+                if (r + 3 < R) load_round2(r + 3);
+                MM_ACC(64 * SRK_MM_CW, 11, tacc);
+                wi = wi == 2 ? 0 : wi + 1;
+                lds_barrier(); // the products of round r; W and Y of round r + 2 are visible
+                MM_ACC(64 * SRK_MM_CW, 12, tacc);
+            }
+#pragma unroll
+            for (int b = 0; b < NBT; ++b)
+                if (i02 < 3 && i02 + 3 * b < 10 && a2 < nf && pl2 < PB) atomicAdd(&sRhs[10 * a2 + i02 + 3 * b], racc2[b]);
+        } else
         for (int r = 0; r < R; ++r) {
             if (r + 2 < R) stage_round(sBuf + wi * WB);
 #ifdef SRK_MM_STAMPS
@@ -1669,23 +1791,36 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int lbase = lk * LDW + lr;
         int ta[SRK_MM_SLOTS], tb[SRK_MM_SLOTS];
         int ns = 0; // this wave's tiles
-        // The full-size grid (nt = 13: 20 frames, the bench scenes) is dealt out as RUNS of eight consecutive tiles: four
-        // consecutive tiles span at most two tile rows, so one or two A operands serve a half step (schur_mm_steps).
-        // (uniform runs only: on ragged runs -- the helpers also mask and rewrite W there -- it made the sum 9 % slower)
-        const bool runs = nt == 13 && !ragged;
+        // The full-size grid (nt = 13: 20 frames, the bench scenes) of a uniform run is dealt out by the table
+        // srk_mm_tiles13: 2 x 4 blocks that share their operands (schur_mm_steps_blk), the rest as rows or single tiles.
+        // (uniform runs only: on ragged runs -- the helpers also mask and rewrite W there -- shared operands made the sum slower)
+        const bool runs = nt == 13 && !ragged, blk = runs && wvu < 9;
+        unsigned onmask = 0; // slots whose sum is flushed (a block's tile above the diagonal is computed, not flushed)
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
-            const int u = runs ? SRK_MM_SLOTS * wvu + s : wvu + SRK_MM_CW * s;
-            const bool on = u < n_tiles;
-            const int uu = on ? u : 0;
-            int ti = (int)((sqrtf(8.0f * (float)uu + 1.0f) - 1.0f) * 0.5f);
-            while ((ti + 1) * (ti + 2) / 2 <= uu) ++ti;
-            while (ti * (ti + 1) / 2 > uu) --ti;
+            int ti, tj;
+            bool on;
+            if (runs) {
+                ti = srk_mm_tiles13[wvu][s][0];
+                tj = srk_mm_tiles13[wvu][s][1];
+                on = ti >= 0 && tj <= ti;
+                if (ti < 0) ti = tj = 0;
+            } else {
+                const int u = wvu + SRK_MM_CW * s;
+                on = u < n_tiles;
+                const int uu = on ? u : 0;
+                ti = (int)((sqrtf(8.0f * (float)uu + 1.0f) - 1.0f) * 0.5f);
+                while ((ti + 1) * (ti + 2) / 2 <= uu) ++ti;
+                while (ti * (ti + 1) / 2 > uu) --ti;
+                tj = uu - ti * (ti + 1) / 2;
+            }
             ta[s] = __builtin_amdgcn_readfirstlane(16 * ti);
-            tb[s] = __builtin_amdgcn_readfirstlane(16 * (uu - ti * (ti + 1) / 2));
+            tb[s] = __builtin_amdgcn_readfirstlane(16 * tj);
             ns += on ? 1 : 0;
+            onmask |= on ? 1u << s : 0u;
         }
         ns = __builtin_amdgcn_readfirstlane(ns);
+        onmask = __builtin_amdgcn_readfirstlane(onmask);
         srk_double4 acc[SRK_MM_SLOTS];
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) acc[s] = (srk_double4){ 0, 0, 0, 0 };
@@ -1698,7 +1833,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         // pattern its row happens to match is fine, its sum is never flushed)
         auto pattern = [&](int s0) {
             const int r0 = ta[s0], r1 = ta[s0 + 1], r2 = ta[s0 + 2], r3 = ta[s0 + 3];
-            if (!runs) return 0;
+            if (!runs || blk) return 0;
             if (r0 == r1 && r1 == r2 && r2 == r3) return 4;
             if (r0 == r1 && r1 == r2) return 31;
             if (r0 == r1 && r2 == r3) return 22;
@@ -1710,7 +1845,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             int wi = 0; // W buffer of round r
             for (int r = 0; r < R; ++r) {
                 const double* bw = sBuf + wi * WB;
-                const double* by = sBuf + (3 + (r & 1)) * WB;
+                const double* by = sBuf + (3 + (ragged ? (r & 1) : wi)) * WB; // uniform runs: Y triple-buffered with W
                 wi = wi == 2 ? 0 : wi + 1;
 #ifdef SRK_SCH_NOACC
                 if (d.N < 0)
@@ -1723,11 +1858,28 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 MM_ACC(0, 7, tacc);
             }
         };
-        {
+        if (blk) {
+            int wi = 0;
+            for (int r = 0; r < R; ++r) {
+                const double* bw = sBuf + wi * WB;
+                const double* by = sBuf + (3 + wi) * WB; // (uniform runs: Y triple-buffered with W)
+                wi = wi == 2 ? 0 : wi + 1;
+#ifdef SRK_SCH_NOACC
+                if (d.N < 0)
+#endif
+                schur_mm_steps_blk(acc, bw, by, ta, tb, lbase);
+                MM_ACC(0, 6, tacc);
+#ifndef SRK_MM_NO_ROUND_BARRIER
+                lds_barrier();
+#endif
+                MM_ACC(0, 7, tacc);
+            }
+        } else {
             using std::integral_constant;
 #define SRK_MM_CASE(A, B) case 100 * A + B: rounds(integral_constant<int, A>{}, integral_constant<int, B>{}); break
             switch (pat) { // the patterns of the nt = 13 runs; anything else takes the general form
             SRK_MM_CASE(4, 4);
+            SRK_MM_CASE(4, 0);
             SRK_MM_CASE(4, 13);
             SRK_MM_CASE(4, 22);
             SRK_MM_CASE(4, 31);
@@ -1747,7 +1899,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             lds_barrier();
 #pragma unroll
             for (int s = 0; s < SRK_MM_SLOTS; ++s) {
-                if (s >= ns) continue;
+                if (!((onmask >> s) & 1u)) continue;
                 const int ti = ta[s] >> 4, tj = tb[s] >> 4; // wave-uniform
                 if (ti >= t0 && ti < t0 + TR) {
 #pragma unroll

@@ -8,4 +8,4 @@ ba = sa.BundleAdjustmentKanatani(0); ba.set_profile(0)
 assert ba.upload(spec.f0, sc)
 ba.optimize(None, max_iterations=2); ba.reset()
 print("---- timed run", file=sys.stderr)
-ba.optimize(None, max_iterations=10)
+ba.optimize(None, max_iterations=int(os.environ.get("SRK_TRACE_K", "10")))
