@@ -40,6 +40,14 @@ void orc_set_w_storage_f32(int on) { orc_w_f32 = on != 0; }
 static int orc_skip_solve = 0;
 void orc_set_skip_solve(int on) { orc_skip_solve = on != 0; }
 int orc_get_threads(void) { return orc_threads; }
+/* Solver of the two-phase step inside orc_compute_inplace: 0 (default, what every parity test pins) = the reference's
+ * Householder QR on dense storage (BA:1911); 1 = BASELINE.md baseline variant (ii), "what a competent CPU port would do":
+ * the same Schur arithmetic on skyline storage and a skyline Cholesky (orc_two_phase_skyline).  Used by bench.py's
+ * cpu_baseline leg for a complete iteration of the 1000-camera scene (its 9993^2 QR would take hours) and checked
+ * against the QR on the small configurations by tests/test_oracle_skyline.py. */
+static int orc_solver = 0;
+void orc_set_solver(int mode) { orc_solver = mode == 1 ? 1 : 0; }
+int orc_get_solver(void) { return orc_solver; }
 
 static double now_sec(void)
 {
@@ -809,6 +817,43 @@ static int64_t* gauge_map(int32_t M, int32_t comp)
     return red;
 }
 
+/* back substitution BA:1919-1960 and gap fill BA:1600-1679 (shared by the QR and the skyline-Cholesky variants) */
+static int two_phase_backsub(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* obs_frame, const double* gradE,
+                             const double* Vpp, const double* Wpf, double c, const int64_t* red, const double* dc,
+                             double* corrections)
+{
+    memset(corrections, 0, sizeof(double) * (size_t)(3 * N + 10 * (int64_t)M));
+    int all_finite = 1;
+#pragma omp parallel for schedule(static) num_threads(orc_threads) reduction(&& : all_finite) if (orc_threads > 1)
+    for (int64_t i = 0; i < N; ++i) {
+        double E[9], Einv[9], det;
+        memcpy(E, Vpp + 9 * i, sizeof E);
+        E[0] *= 1 + c; E[4] *= 1 + c; E[8] *= 1 + c;
+        double* dx = corrections + 3 * i;
+        if (!orc_inverse3x3_with_check(E, Einv, &det)) { dx[0] = dx[1] = dx[2] = 0; continue; }
+        const double* g = gradE + 3 * i;
+        double acc[3] = { 0, 0, 0 };
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o)
+            for (int fv = 0; fv < 10; ++fv) {
+                int64_t r = red[10 * (int64_t)obs_frame[o] + fv];
+                if (r < 0) continue;
+                for (int pv = 0; pv < 3; ++pv) acc[pv] += Wpf[30 * o + 10 * pv + fv] * dc[r];
+            }
+        double b[3] = { acc[0] + g[0], acc[1] + g[1], acc[2] + g[2] };
+        for (int pv = 0; pv < 3; ++pv) {
+            dx[pv] = -Einv[3 * pv] * b[0] - Einv[3 * pv + 1] * b[1] - Einv[3 * pv + 2] * b[2];
+            if (!isfinite(dx[pv])) all_finite = 0; /* :1953-1954 (the reference stops at the first; the result is discarded either way) */
+        }
+    }
+    for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi) corrections[3 * N + fi] = red[fi] >= 0 ? dc[red[fi]] : 0.0;
+    return all_finite;
+}
+
+int orc_two_phase_skyline(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* obs_frame, const double* gradE,
+                          const double* Vpp, const double* Uff, const double* Wpf, double c, int32_t comp,
+                          double* corrections, const int64_t* sel_rows, int64_t n_sel, double* S_rows_out,
+                          double* rhs_out, double* sec_schur, double* sec_solve, double* sec_backsub);
+
 /* ---------------------------------------------------------------- two-phase solve */
 
 /* BA:1771-1995 EstimateCorrectionsDecomposedInTwoPhases (+ :1600-1679 FillCorrectionsGapsFromNormalized) */
@@ -817,6 +862,9 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
                   int32_t dense_literal, double* corrections, double* S_out, double* rhs_out, double* sec_schur,
                   double* sec_solve, double* sec_backsub)
 {
+    if (orc_solver == 1 && !dense_literal && !S_out && !rhs_out)
+        return orc_two_phase_skyline(N, M, row_ptr, obs_frame, gradE, Vpp, Uff, Wpf, c, comp, corrections, NULL, 0, NULL,
+                                     NULL, sec_schur, sec_solve, sec_backsub);
     int64_t n = 10 * (int64_t)M - 7;
     int64_t* red = gauge_map(M, comp);
     double t0 = now_sec();
@@ -958,34 +1006,7 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
     if (orc_skip_solve) memset(dc, 0, sizeof(double) * (size_t)n);
     else ok = orc_householder_qr_solve(n, S, rhs, dc);
     double t2 = now_sec();
-    if (ok) {
-        /* back substitution BA:1919-1960 and gap fill BA:1600-1679 */
-        memset(corrections, 0, sizeof(double) * (size_t)(3 * N + 10 * (int64_t)M));
-        int all_finite = 1;
-#pragma omp parallel for schedule(static) num_threads(orc_threads) reduction(&& : all_finite) if (orc_threads > 1)
-        for (int64_t i = 0; i < N; ++i) {
-            double E[9], Einv[9], det;
-            memcpy(E, Vpp + 9 * i, sizeof E);
-            E[0] *= 1 + c; E[4] *= 1 + c; E[8] *= 1 + c;
-            double* dx = corrections + 3 * i;
-            if (!orc_inverse3x3_with_check(E, Einv, &det)) { dx[0] = dx[1] = dx[2] = 0; continue; }
-            const double* g = gradE + 3 * i;
-            double acc[3] = { 0, 0, 0 };
-            for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o)
-                for (int fv = 0; fv < 10; ++fv) {
-                    int64_t r = red[10 * (int64_t)obs_frame[o] + fv];
-                    if (r < 0) continue;
-                    for (int pv = 0; pv < 3; ++pv) acc[pv] += Wpf[30 * o + 10 * pv + fv] * dc[r];
-                }
-            double b[3] = { acc[0] + g[0], acc[1] + g[1], acc[2] + g[2] };
-            for (int pv = 0; pv < 3; ++pv) {
-                dx[pv] = -Einv[3 * pv] * b[0] - Einv[3 * pv + 1] * b[1] - Einv[3 * pv + 2] * b[2];
-                if (!isfinite(dx[pv])) all_finite = 0; /* :1953-1954 (the reference stops at the first; the result is discarded either way) */
-            }
-        }
-        ok = all_finite;
-        for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi) corrections[3 * N + fi] = red[fi] >= 0 ? dc[red[fi]] : 0.0;
-    }
+    if (ok) ok = two_phase_backsub(N, M, row_ptr, obs_frame, gradE, Vpp, Wpf, c, red, dc, corrections);
     double t3 = now_sec();
     if (sec_schur) *sec_schur += t1 - t0;
     if (sec_solve) *sec_solve += t2 - t1;
@@ -996,6 +1017,193 @@ int orc_two_phase(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* o
     free(S);
     free(rhs);
     free(red);
+    return ok;
+}
+
+
+/* ---------------------------------------------------------------- two-phase solve, baseline variant (ii)
+ * the reference's arithmetic (BA:1771-1995) on block-sparse storage with the solver a CPU port
+ * would use.  The reduced camera system is kept as a row skyline: row r (reduced index, frame j) starts at the first
+ * reduced variable of the smallest frame that shares a landmark with j -- everything left of it is structurally zero and
+ * Cholesky fill stays inside such an envelope.  The Schur sum is the loop of orc_two_phase restricted to the lower
+ * triangle, term by term in the same order, so every stored entry carries the same bits as the dense S there
+ * (tests/test_oracle_skyline.py).  The solve is a skyline Cholesky (the damped system is positive definite)
+ * instead of BA:1911's Householder QR; a non-positive pivot or a non-finite solution returns 0 like the QR's non-finite
+ * result does (:1912-1913).  sel_rows / S_rows_out: optional dump of selected rows of the system BEFORE the factorisation
+ * (n_sel rows of n doubles, columns <= row filled, the rest zero) -- lets a test compare a 40 000-variable system on a
+ * sample of rows without a 12.8 GB dense copy. */
+int orc_two_phase_skyline(int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* obs_frame, const double* gradE,
+                          const double* Vpp, const double* Uff, const double* Wpf, double c, int32_t comp,
+                          double* corrections, const int64_t* sel_rows, int64_t n_sel, double* S_rows_out,
+                          double* rhs_out, double* sec_schur, double* sec_solve, double* sec_backsub)
+{
+    const int64_t n = 10 * (int64_t)M - 7;
+    int64_t* red = gauge_map(M, comp);
+    double t0 = now_sec();
+    /* covisibility: smallest frame sharing a landmark with frame j (frame lists are ascending) */
+    int32_t* mincv = (int32_t*)malloc(sizeof(int32_t) * (size_t)M);
+    for (int32_t j = 0; j < M; ++j) mincv[j] = j;
+    for (int64_t i = 0; i < N; ++i) {
+        if (row_ptr[i + 1] == row_ptr[i]) continue;
+        const int32_t f0i = obs_frame[row_ptr[i]];
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o)
+            if (f0i < mincv[obs_frame[o]]) mincv[obs_frame[o]] = f0i;
+    }
+    int64_t* first = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    off[0] = 0;
+    for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi) {
+        const int64_t r = red[fi];
+        if (r < 0) continue;
+        int64_t ff = 10 * (int64_t)mincv[fi / 10];
+        while (red[ff] < 0) ++ff; /* stops at fi at the latest: fi itself is kept */
+        first[r] = red[ff];
+        off[r + 1] = off[r] + (r - first[r] + 1);
+    }
+    double* L = (double*)calloc((size_t)off[n], sizeof(double));
+    double* rhs = (double*)calloc((size_t)n, sizeof(double));
+#define SK(r, cc) L[off[r] + ((cc) - first[r])]
+    /* fill_matG BA:1780-1823, lower triangle */
+    for (int32_t j = 0; j < M; ++j) {
+        const double* U = Uff + 100 * (int64_t)j;
+        for (int v1 = 0; v1 < 10; ++v1) {
+            const int64_t r1 = red[10 * (int64_t)j + v1];
+            if (r1 < 0) continue;
+            for (int v2 = 0; v2 < 10; ++v2) {
+                const int64_t r2 = red[10 * (int64_t)j + v2];
+                if (r2 < 0 || r2 > r1) continue;
+                double val = U[10 * v1 + v2];
+                if (v1 == v2) val *= 1 + c; /* :1818-1819 */
+                SK(r1, r2) = val;
+            }
+        }
+    }
+    /* per point BA:1862-1898, the terms of orc_two_phase in its order; threads > 1: frame-major as there (a thread owns
+     * the rows of its frames) */
+    if (orc_threads > 1) {
+        double* Einv_all = (double*)malloc(sizeof(double) * (size_t)(9 * (N > 0 ? N : 1)));
+        char* ok_all = (char*)malloc((size_t)(N > 0 ? N : 1));
+#pragma omp parallel for schedule(static) num_threads(orc_threads)
+        for (int64_t i = 0; i < N; ++i) {
+            double E[9], det;
+            memcpy(E, Vpp + 9 * i, sizeof E);
+            E[0] *= 1 + c; E[4] *= 1 + c; E[8] *= 1 + c;
+            ok_all[i] = (char)orc_inverse3x3_with_check(E, Einv_all + 9 * i, &det);
+        }
+        csc_t cs;
+        csc_build(N, M, row_ptr, obs_frame, &cs);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(orc_threads)
+        for (int32_t j = 0; j < M; ++j) {
+            for (int64_t k = cs.col_ptr[j]; k < cs.col_ptr[j + 1]; ++k) {
+                const int64_t oa = cs.obs[k], i = cs.pnt[k];
+                if (!ok_all[i]) continue;
+                const double* Einv = Einv_all + 9 * i;
+                const double* g = gradE + 3 * i;
+                const double* Wa = Wpf + 30 * oa;
+                double tmp[10][3];
+                for (int fa = 0; fa < 10; ++fa)
+                    for (int kk = 0; kk < 3; ++kk)
+                        tmp[fa][kk] = Wa[fa] * Einv[0 * 3 + kk] + Wa[10 + fa] * Einv[1 * 3 + kk] + Wa[20 + fa] * Einv[2 * 3 + kk];
+                for (int fa = 0; fa < 10; ++fa) {
+                    const int64_t ra = red[10 * (int64_t)j + fa];
+                    if (ra < 0) continue;
+                    for (int64_t ob = row_ptr[i]; ob < row_ptr[i + 1]; ++ob) {
+                        const double* Wb = Wpf + 30 * ob;
+                        for (int fb = 0; fb < 10; ++fb) {
+                            const int64_t rb = red[10 * (int64_t)obs_frame[ob] + fb];
+                            if (rb < 0 || rb > ra) continue;
+                            SK(ra, rb) -= tmp[fa][0] * Wb[fb] + tmp[fa][1] * Wb[10 + fb] + tmp[fa][2] * Wb[20 + fb];
+                        }
+                    }
+                    rhs[ra] += tmp[fa][0] * g[0] + tmp[fa][1] * g[1] + tmp[fa][2] * g[2];
+                }
+            }
+        }
+        csc_free(&cs);
+        free(Einv_all);
+        free(ok_all);
+    } else
+    for (int64_t i = 0; i < N; ++i) {
+        double E[9], Einv[9], det;
+        memcpy(E, Vpp + 9 * i, sizeof E);
+        E[0] *= 1 + c; E[4] *= 1 + c; E[8] *= 1 + c; /* :1825-1834 */
+        if (!orc_inverse3x3_with_check(E, Einv, &det)) continue; /* :1877-1881 */
+        const double* g = gradE + 3 * i;
+        const int64_t o0 = row_ptr[i], o1 = row_ptr[i + 1];
+        for (int64_t oa = o0; oa < o1; ++oa) {
+            const double* Wa = Wpf + 30 * oa;
+            double tmp[10][3];
+            for (int fa = 0; fa < 10; ++fa)
+                for (int k = 0; k < 3; ++k)
+                    tmp[fa][k] = Wa[fa] * Einv[0 * 3 + k] + Wa[10 + fa] * Einv[1 * 3 + k] + Wa[20 + fa] * Einv[2 * 3 + k];
+            for (int fa = 0; fa < 10; ++fa) {
+                const int64_t ra = red[10 * (int64_t)obs_frame[oa] + fa];
+                if (ra < 0) continue;
+                for (int64_t ob = o0; ob < o1; ++ob) {
+                    const double* Wb = Wpf + 30 * ob;
+                    for (int fb = 0; fb < 10; ++fb) {
+                        const int64_t rb = red[10 * (int64_t)obs_frame[ob] + fb];
+                        if (rb < 0 || rb > ra) continue;
+                        SK(ra, rb) -= tmp[fa][0] * Wb[fb] + tmp[fa][1] * Wb[10 + fb] + tmp[fa][2] * Wb[20 + fb];
+                    }
+                }
+                rhs[ra] += tmp[fa][0] * g[0] + tmp[fa][1] * g[1] + tmp[fa][2] * g[2];
+            }
+        }
+    }
+    for (int64_t fi = 0; fi < 10 * (int64_t)M; ++fi) /* BA:1902-1908 */
+        if (red[fi] >= 0) rhs[red[fi]] -= gradE[3 * N + fi];
+    if (S_rows_out)
+        for (int64_t s = 0; s < n_sel; ++s) {
+            const int64_t r = sel_rows[s];
+            memset(S_rows_out + s * n, 0, sizeof(double) * (size_t)n);
+            if (r < 0 || r >= n) continue;
+            memcpy(S_rows_out + s * n + first[r], &SK(r, first[r]), sizeof(double) * (size_t)(r - first[r] + 1));
+        }
+    if (rhs_out) memcpy(rhs_out, rhs, sizeof(double) * (size_t)n);
+    double t1 = now_sec();
+    /* skyline Cholesky, row by row: L_ij = (a_ij - sum_k L_ik L_jk) / L_jj over the common part of rows i and j */
+    double* dc = (double*)malloc(sizeof(double) * (size_t)n);
+    int ok = 1;
+    if (orc_skip_solve) memset(dc, 0, sizeof(double) * (size_t)n);
+    else {
+        for (int64_t i = 0; i < n && ok; ++i) {
+            double* Li = L + off[i] - first[i];
+            for (int64_t j = first[i]; j <= i; ++j) {
+                const double* Lj = L + off[j] - first[j];
+                const int64_t k0 = first[i] > first[j] ? first[i] : first[j];
+                double sum = Li[j];
+                for (int64_t k = k0; k < j; ++k) sum -= Li[k] * Lj[k];
+                if (j < i) Li[j] = sum / Lj[j];
+                else if (!(sum > 0) || !isfinite(sum)) { ok = 0; break; }
+                else Li[i] = sqrt(sum);
+            }
+        }
+        if (ok) {
+            for (int64_t i = 0; i < n; ++i) { /* L y = rhs */
+                const double* Li = L + off[i] - first[i];
+                double sum = rhs[i];
+                for (int64_t k = first[i]; k < i; ++k) sum -= Li[k] * dc[k];
+                dc[i] = sum / Li[i];
+            }
+            for (int64_t i = n - 1; i >= 0; --i) { /* L^T x = y */
+                const double* Li = L + off[i] - first[i];
+                const double xi = dc[i] / Li[i];
+                dc[i] = xi;
+                for (int64_t k = first[i]; k < i; ++k) dc[k] -= Li[k] * xi;
+            }
+            for (int64_t i = 0; i < n; ++i)
+                if (!isfinite(dc[i])) { ok = 0; break; } /* :1912-1913 */
+        }
+    }
+#undef SK
+    double t2 = now_sec();
+    if (ok) ok = two_phase_backsub(N, M, row_ptr, obs_frame, gradE, Vpp, Wpf, c, red, dc, corrections);
+    double t3 = now_sec();
+    if (sec_schur) *sec_schur += t1 - t0;
+    if (sec_solve) *sec_solve += t2 - t1;
+    if (sec_backsub) *sec_backsub += t3 - t2;
+    free(dc); free(L); free(rhs); free(first); free(off); free(mincv); free(red);
     return ok;
 }
 

@@ -183,6 +183,35 @@ def two_phase(sc, gradE, V, U, W, c, comp=1, dense_literal=False, want_system=Fa
     return bool(ok), corr
 
 
+def two_phase_skyline(sc, gradE, V, U, W, c, comp=1, sel_rows=None, want_rhs=False):
+    """Baseline variant (ii): the two-phase step on skyline storage with a skyline Cholesky (ba_oracle.c:
+    orc_two_phase_skyline).  sel_rows: reduced row indices whose rows of the system (before the factorisation, columns <=
+    row filled) are returned as an [len(sel_rows), 10M-7] array.  Returns (ok, corrections[, rows][, rhs])."""
+    N, M = sc.N, sc.M
+    n = 10 * M - 7
+    corr = np.zeros(3 * N + 10 * M)
+    sel = np.ascontiguousarray(sel_rows, dtype=np.int64) if sel_rows is not None else None
+    rows = np.zeros((len(sel), n)) if sel is not None else None
+    rhs = np.zeros(n) if want_rhs else None
+    f = lib().orc_two_phase_skyline
+    f.restype = C.c_int
+    ok = f(C.c_int64(N), C.c_int32(M), _i64(sc.row_ptr), _i32(sc.obs_frame), _d(gradE), _d(V), _d(U), _d(W), C.c_double(c),
+           C.c_int32(comp), _d(corr), _i64(sel) if sel is not None else None, C.c_int64(len(sel) if sel is not None else 0),
+           _d(rows) if rows is not None else None, _d(rhs) if rhs is not None else None, None, None, None)
+    out = (bool(ok), corr)
+    if rows is not None:
+        out += (rows,)
+    if rhs is not None:
+        out += (rhs,)
+    return out
+
+
+def set_solver(mode):
+    """0 = the reference's Householder QR (default, what the parity tests pin); 1 = skyline Cholesky inside compute_inplace
+    (BASELINE.md baseline variant (ii); bench.py's cpu_baseline leg)."""
+    lib().orc_set_solver(C.c_int(int(mode)))
+
+
 def naive_solve(sc, gradE, V, U, W, c, comp=1):
     corr = np.zeros(3 * sc.N + 10 * sc.M)
     ok = lib().orc_naive_solve(C.c_int64(sc.N), C.c_int32(sc.M), _i64(sc.row_ptr), _i32(sc.obs_frame), _d(gradE),

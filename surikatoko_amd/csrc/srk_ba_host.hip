@@ -262,7 +262,9 @@ void srk_ba_destroy(srk_ba* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->att[1].stream) hipStreamSynchronize(h->att[1].stream);
+    if (h->comm2) rccl().CommDestroy(h->comm2); // the second slot's communicator is always owned by the handle
     if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
+    h->comm = h->comm2 = nullptr;
     DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->pts[2], &h->camR[0], &h->camR[1], &h->camR[2], &h->camT[0], &h->camT[1],
                       &h->camT[2], &h->K, &h->cam[0], &h->cam[1], &h->cam[2], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
@@ -318,6 +320,17 @@ int srk_ba_set_stream(srk_ba* h, void* hip_stream)
 int srk_ba_set_allreduce(srk_ba* h, srk_allreduce_fn fn, void* ctx, int rank, int world_size)
 {
     if (!h || world_size < 1 || rank < 0 || rank >= world_size) return SRK_E_ARGS;
+    // either exchange replaces the other: exchange() prefers a communicator, so a callback set after srk_ba_rccl_init
+    // would never be called unless the communicators are detached here
+    if (h->comm || h->comm2) {
+        hipSetDevice(h->device);
+        if (h->stream) hipStreamSynchronize(h->stream);
+        if (h->att[1].stream) hipStreamSynchronize(h->att[1].stream);
+        if (h->comm2) rccl().CommDestroy(h->comm2);
+        if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
+        h->comm = h->comm2 = nullptr;
+        h->comm_owned = false;
+    }
     h->allreduce = fn;
     h->allreduce_ctx = ctx;
     h->rank = rank;

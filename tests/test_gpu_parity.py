@@ -9,7 +9,7 @@ import pytest
 
 import surikatoko_amd as sa
 from surikatoko_amd import ba as B
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, sym_scaled_err, class_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,33 @@ def _phases(orc, gpu, sc, f0, c, already_normalized=False):
     return out
 
 
+def _check_blocks_by_class(V_g, V_o, U_g, U_o, W_g, W_o, gradE_g, gradE_o, err):
+    """Derivative blocks on the scale of each variable class (conftest: per-variable-class metrics): point and frame
+    blocks with rows / columns scaled by 1 / sqrt(diag) of the oracle's block (1e-12: the u0 / v0 and the intrinsics x
+    intrinsics entries are pinned to 1e-12 of THEIR scale, not of the pose entries'), point-frame blocks per (point
+    coordinate, frame variable) class (1e-12), gradient entries on their Cauchy-Schwarz scale 2 sqrt(E B_aa) (1e-10)."""
+    N, M = V_o.shape[0], U_o.shape[0]
+    dV = np.sqrt(np.abs(np.einsum("nii->ni", V_o)))
+    dU = np.sqrt(np.abs(np.einsum("mii->mi", U_o)))
+    assert sym_scaled_err(V_g, V_o, dV) < 1e-12
+    assert sym_scaled_err(U_g, U_o, dU) < 1e-12
+    assert class_rel_err(W_g, W_o, (1, 2)) < 1e-12
+    gs = 2.0 * np.sqrt(max(err, 1e-300))
+    dg = np.concatenate([dV.reshape(-1), dU.reshape(-1)]) * gs
+    ok = dg > 0
+    assert float((np.abs(gradE_g - gradE_o)[ok] / dg[ok]).max()) < 1e-10
+    return dU.reshape(-1)
+
+
+def _check_system_by_class(S_g, S_o, rhs_g, rhs_o, dU_keep, err, tol=1e-10):
+    """Reduced camera system and right-hand side with every row / column on the scale of its variable: divided by
+    sqrt(diag) of the oracle's (undamped) frame blocks -- the magnitude of the terms the Schur sums add up."""
+    assert sym_scaled_err(S_g, S_o, dU_keep) < tol
+    gs = 2.0 * np.sqrt(max(err, 1e-300))
+    ok = dU_keep > 0
+    assert float((np.abs(rhs_g - rhs_o)[ok] / (dU_keep[ok] * gs)).max()) < tol
+
+
 def _check(out, M, corr_tol=1e-8):
     assert out["seen_g"] == out["seen_o"]
     assert out["err_g"] == pytest.approx(out["err_o"], rel=1e-12)
@@ -97,6 +124,10 @@ def _check(out, M, corr_tol=1e-8):
     Sg = out["S_g"][np.ix_(keep, keep)]
     assert rel_err(Sg, out["S_o"]) < 1e-10
     assert rel_err(out["rhs_g"][keep], out["rhs_o"]) < 1e-10
+    # the same, every entry on the scale of its own variable class
+    dU = _check_blocks_by_class(out["V_g"], out["V_o"], out["U_g"], out["U_o"], out["W_g"], out["W_o"], out["gradE_g"],
+                                out["gradE_o"], out["err_o"])
+    _check_system_by_class(Sg, out["S_o"], out["rhs_g"][keep], out["rhs_o"], dU[keep], out["err_o"])
     # gauge-fixed variables: identity rows, zero rhs
     fixed = np.where(~keep)[0]
     for f in fixed:
@@ -630,11 +661,13 @@ def test_c3_full_size_blocks_and_reduced_system_vs_oracle(orc, gpu):
     assert seen_g == seen_o == 2000000 and eg == pytest.approx(eo, rel=1e-12)
     gradE, V, U, W = orc.derivatives(spec.f0, so)
     gpu.phase_derivatives()
-    assert rel_err(gpu.buffer(B.BUF_POINT_BLOCKS).reshape(-1, 3, 3), V) < 1e-12
-    assert rel_err(gpu.buffer(B.BUF_FRAME_BLOCKS).reshape(-1, 10, 10), U) < 1e-12
-    assert rel_err(gpu.buffer(B.BUF_GRAD), gradE) < 1e-10
+    Vg_, Ug_, gg_ = gpu.buffer(B.BUF_POINT_BLOCKS).reshape(-1, 3, 3), gpu.buffer(B.BUF_FRAME_BLOCKS).reshape(-1, 10, 10), gpu.buffer(B.BUF_GRAD)
+    assert rel_err(Vg_, V) < 1e-12
+    assert rel_err(Ug_, U) < 1e-12
+    assert rel_err(gg_, gradE) < 1e-10
     Wg = gpu.buffer(B.BUF_POINT_FRAME).reshape(-1, 3, 10)
     assert rel_err(Wg, W) < 1e-12
+    dU = _check_blocks_by_class(Vg_, V, Ug_, U, Wg, W, gg_, gradE, eo)  # every entry on the scale of its variable class
     del Wg
     orc.set_skip_solve(True)   # the system is formed, the QR is not run
     try:
@@ -650,11 +683,17 @@ def test_c3_full_size_blocks_and_reduced_system_vs_oracle(orc, gpu):
     Sg = gpu.buffer(B.BUF_RCS).reshape(10 * M, 10 * M)
     idx = np.where(keep)[0]
     scale = float(np.abs(S).max())
-    worst = 0.0
+    dk = dU[keep]
+    worst = worst_scaled = 0.0
     for r0 in range(0, len(idx), 1000):          # row blocks: no second 800 MB copy
         rows = idx[r0:r0 + 1000]
-        worst = max(worst, float(np.abs(Sg[np.ix_(rows, idx)] - S[r0:r0 + 1000]).max()))
+        diff = np.abs(Sg[np.ix_(rows, idx)] - S[r0:r0 + 1000])
+        worst = max(worst, float(diff.max()))
+        worst_scaled = max(worst_scaled, float((diff / (dk[r0:r0 + 1000, None] * dk[None, :])).max()))
     assert worst < 1e-10 * scale
+    assert worst_scaled < 1e-10                   # rows / columns on the scale of their variable (1 / sqrt(diag U))
+    gs = 2.0 * np.sqrt(eo)
+    assert float((np.abs(rg[keep] - rhs) / (dk * gs)).max()) < 1e-10
     gpu.upload(SCENES["tiny"].f0, sa.generate_scene(SCENES["tiny"]))  # release the large buffers
 
 
@@ -793,6 +832,32 @@ def test_native_rccl_two_communicators_keep_the_attempt_pairs_world_size_1(orc):
         assert ba.solver_sync_timeouts() == 0
     finally:
         ba.close()
+
+
+def test_native_rccl_handles_release_both_communicators():
+    """srk_ba_destroy / srk_ba_set_allreduce release the second slot's communicator as well as the first (it used to leak
+    with every handle that had used the two-communicator path): create / init both / close in a loop at world size 1, and
+    a callback set after the communicators replaces them."""
+    spec = SCENES["tiny"]
+    sc = sa.generate_scene(spec)
+    for k in range(6):
+        ba = sa.BundleAdjustmentKanatani(0)
+        try:
+            ba.rccl_init(ba.rccl_unique_id(), 0, 1)
+            ba.rccl_init_second(ba.rccl_unique_id())
+            if k % 2:
+                calls = []
+                from surikatoko_amd._lib import ALLREDUCE_FN
+                hook = ALLREDUCE_FN(lambda ctx, ptr, n: calls.append(n) or 0)
+                ba.set_allreduce(hook, 0, 1)  # detaches (and destroys) both communicators
+            crit = sa.BundleAdjustmentKanataniTermCriteria()
+            crit.AllowedReprojErrRelativeChange(1e-7)
+            ba.ComputeInplace(spec.f0, sc.copy(), crit, 3)
+            assert ba.report.iterations >= 1
+            if k % 2:
+                assert calls, "the callback set after srk_ba_rccl_init must be the exchange that runs"
+        finally:
+            ba.close()
 
 
 def test_allreduce_hook_with_device_pointers(orc, gpu):
