@@ -227,6 +227,9 @@ enum srk_buffer {
 };
 int64_t srk_ba_buffer_size(srk_ba*, int which);                 /* doubles; negative on error */
 int srk_ba_download(srk_ba*, int which, double* dst, int64_t count);
+/* selected rows of the padded reduced camera system (SRK_BUF_RCS is 12.8 GB at 4000 frames): dst[n_rows][10M], row
+ * rows[k] of the system with its columns <= the row filled (the lower triangle is authoritative), zeros right of it */
+int srk_ba_download_rcs_rows(srk_ba*, const int64_t* rows, int64_t n_rows, double* dst);
 
 /* The reduced camera system is non-zero only where two frames share a landmark; the solver skips everything
  * outside that skyline (exact: Cholesky fill stays inside it).  With landmark shards every rank must be given the

@@ -59,7 +59,7 @@ EXPORTS = [
     "srk_ba_normalize_scene", "srk_ba_revert_normalization", "srk_ba_check_world_is_normalized",
     "srk_ba_upload_scene", "srk_ba_optimize", "srk_ba_download_scene", "srk_ba_reset_scene", "srk_ba_phase_error",
     "srk_ba_phase_derivatives", "srk_ba_phase_schur", "srk_ba_phase_solve", "srk_ba_phase_backsub",
-    "srk_ba_phase_accept", "srk_ba_buffer_size", "srk_ba_download", "srk_ba_set_profile", "srk_ba_dense_spd_solve",
+    "srk_ba_phase_accept", "srk_ba_buffer_size", "srk_ba_download", "srk_ba_download_rcs_rows", "srk_ba_set_profile", "srk_ba_dense_spd_solve",
     "srk_ba_set_covisibility", "srk_ba_set_rcs_mode", "srk_ba_rcs_fill", "srk_ba_solve_mfma_flops", "srk_ba_rcs_chunks",
     "srk_scene_num_observations", "srk_scene_generate", "srk_circle_camera_shots",
     "srk_read_matrix_file", "srk_decompose_proj_mat", "srk_triangulate_least_squares", "srk_dino_load",

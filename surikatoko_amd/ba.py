@@ -391,6 +391,14 @@ class BundleAdjustmentKanatani:
         self._raise(self._lib.srk_ba_download(C.c_void_p(self._h), int(which), _p(out), C.c_int64(n)))
         return out
 
+    def rcs_rows(self, rows):
+        """rows of the padded reduced camera system (full frame-variable indexing, columns <= row filled)"""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.zeros((len(rows), 10 * self._scene.M))
+        self._raise(self._lib.srk_ba_download_rcs_rows(C.c_void_p(self._h), rows.ctypes.data_as(C.c_void_p),
+                                                       C.c_int64(len(rows)), _p(out)))
+        return out
+
     def dense_spd_solve(self, A, b):
         A = np.ascontiguousarray(A, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -80,6 +80,7 @@ struct srk_ba {
     // damping factor speculatively beside the current one (the solve is a latency chain that leaves the chip idle).
     struct Attempt {
         DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv, packed, sync_flags;
+        DevBuf irr; // [0] count + landmarks the SYRK form of k_schur_mm hands back to the per-landmark inverse path
         SrkChunkPlan plan;
         SrkCholSync sync;            // in-launch hand-offs of the fused outer-step kernel (srk_chol.hip: k_step256)
         std::vector<DevBuf> plan_bufs;
@@ -274,7 +275,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
-        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed, &a.sync_flags }) dev_free(*b);
+        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
@@ -1018,6 +1019,8 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         ALLOC(a.err_out, 64);
         ALLOC(a.info, 64);
         ALLOC(a.dinv, 8 * 64 * d.ld);
+        ALLOC(a.irr, 4 * (N + 2));
+        HIPCHK(h, hipMemsetAsync(a.irr.p, 0, 4, h->stream));
         if (!a.sync_flags.p) { // flag words of the fused outer-step kernel: zeroed ONCE (they hold launch epochs)
             ALLOC(a.sync_flags, 4 * SRK_SYNC_WORDS);
             HIPCHK(h, hipMemset(a.sync_flags.p, 0, 4 * SRK_SYNC_WORDS));
@@ -1254,11 +1257,12 @@ static int phase_schur(srk_ba* h, double c)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
-    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->A->S), P<double>(h->A->rhs)); // S band and rhs
+    srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->A->S), P<double>(h->A->rhs), P<int32_t>(h->A->irr)); // S band, rhs, hand-back counter
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S),
                              P<double>(h->A->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
-                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0);
+                             P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0,
+                             P<int32_t>(h->A->irr));
     srk_launch_schur_long(s, d, c, P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S), P<double>(h->A->rhs),
                           P<int32_t>(h->lg_item), h->n_long_items, P<int32_t>(h->lg_np), P<int32_t>(h->lg_nf), P<int32_t>(h->lg_pts),
                           P<int32_t>(h->lg_frames), P<int64_t>(h->lg_obs_off), P<int32_t>(h->lg_obs));
@@ -1267,7 +1271,8 @@ static int phase_schur(srk_ba* h, double c)
     HIPCHK(h, hipGetLastError());
     // G (frame blocks, damped) and the frame gradients are linear in this rank's landmarks as well, so they are added
     // before the exchange; the identity diagonal of fixed / padding variables comes from rank 0 alone
-    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->A->S), P<double>(h->A->rhs), h->rank == 0 ? 1.0 : 0.0);
+    srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->A->S), P<double>(h->A->rhs), h->rank == 0 ? 1.0 : 0.0,
+                        P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg), P<int32_t>(h->A->irr));
     HIPCHK(h, hipGetLastError());
     if (h->allreduce || h->comm) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
         int rc;
@@ -2109,6 +2114,24 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     case SRK_BUF_CAM_T: return d2h(dst, h->camT[h->cur].p, (size_t)(24 * (int64_t)d.M));
     default: return SRK_E_ARGS;
     }
+}
+
+int srk_ba_download_rcs_rows(srk_ba* h, const int64_t* rows, int64_t n_rows, double* dst)
+{
+    if (!h || !h->have_scene || !rows || !dst || n_rows < 0) return SRK_E_STATE;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->att[1].stream));
+    const SrkDims& d = h->d;
+    const int64_t n = 10 * (int64_t)d.M;
+    const double* S = P<double>(h->att[h->last_slot].S);
+    for (int64_t k = 0; k < n_rows; ++k) {
+        const int64_t r = rows[k];
+        if (r < 0 || r >= n) { h->last_error = "download_rcs_rows: row out of range"; return SRK_E_ARGS; }
+        std::memset(dst + k * n, 0, (size_t)(8 * n));
+        HIPCHK(h, hipMemcpy(dst + k * n, S + r * d.ld, (size_t)(8 * (r + 1)), hipMemcpyDeviceToHost));
+    }
+    return SRK_OK;
 }
 
 // ------------------------------------------------------------------ dense SPD solve on its own

@@ -717,10 +717,120 @@ __device__ __forceinline__ bool point_block_inverse(const double* __restrict__ V
     return true;
 }
 
+// The same block as a Cholesky factor E = L L^T, for the SYRK form of the Schur sum (k_schur_mm on uniform runs):
+//     W^T E^-1 W = Z^T Z,  Z = L^-1 W,      W^T E^-1 g = Z^T (L^-1 g).
+// Lc = { 1/l00, l10, 1/l11, l20, l21, 1/l22 }, h = L^-1 g.  Returns 0: |det| <= 1e-12, the landmark is skipped exactly as
+// with the inverse (:1877-1881); 1: factor formed; 2: the block passes the determinant check but a pivot is not positive
+// (E = V + c diag(V) with V a sum of outer products is positive definite in exact arithmetic, so this needs a damping
+// factor below the rounding level of V) -- the caller hands such a landmark to the per-landmark inverse path, so the sum
+// stays the reference's W^T E^-1 W whatever E is.
+__device__ __forceinline__ int point_block_cholesky(const double* __restrict__ Vg, int64_t Ns, int64_t pt, double c,
+                                                    double Lc[6], double h[3])
+{
+    const double e00 = Vg[0 * Ns + pt] * (1 + c), e01 = Vg[1 * Ns + pt], e02 = Vg[2 * Ns + pt];
+    const double e11 = Vg[3 * Ns + pt] * (1 + c), e12 = Vg[4 * Ns + pt], e22 = Vg[5 * Ns + pt] * (1 + c);
+    const double g0 = Vg[6 * Ns + pt], g1 = Vg[7 * Ns + pt], g2 = Vg[8 * Ns + pt];
+    const double c00 = e11 * e22 - e12 * e12;
+    const double c01 = e12 * e02 - e01 * e22;
+    const double c02 = e01 * e12 - e11 * e02;
+    const double det = e00 * c00 + e01 * c01 + e02 * c02; // the same expression as point_block_inverse: same skip decision
+    if (!(fabs(det) > 1e-12)) return 0;
+    const double l00 = sqrt(e00), i0 = 1 / l00;
+    const double l10 = e01 * i0, l20 = e02 * i0;
+    const double d1 = e11 - l10 * l10;
+    const double l11 = sqrt(d1), i1 = 1 / l11;
+    const double l21 = (e12 - l20 * l10) * i1;
+    const double d2 = e22 - l20 * l20 - l21 * l21;
+    const double l22 = sqrt(d2), i2 = 1 / l22;
+    if (!(e00 > 0 && d1 > 0 && d2 > 0) || !isfinite(i0) || !isfinite(i1) || !isfinite(i2)) return 2;
+    Lc[0] = i0; Lc[1] = l10; Lc[2] = i1; Lc[3] = l20; Lc[4] = l21; Lc[5] = i2;
+    h[0] = g0 * i0;
+    h[1] = (g1 - l10 * h[0]) * i1;
+    h[2] = (g2 - l20 * h[0] - l21 * h[1]) * i2;
+    return 1;
+}
+
 // ------------------------------------------------------------------ K3: Schur accumulation (per landmark)
 // One workgroup per landmark: 3x3 elimination block inverted in registers, W_i staged in LDS, Y = E^-1 W_i in LDS,
 // then the n_i(n_i+1)/2 lower 10x10 outer-product blocks are subtracted from S with fp64 atomics.
 #define SRK_SCH 32 // observations per LDS chunk
+
+// one landmark by the whole 256-thread workgroup (k_schur; and the tail workgroups of k_assemble for the landmarks the
+// SYRK form of k_schur_mm hands back)
+struct SchurLmScratch {
+    double sWa[SRK_SCH][30];
+    double sYb[SRK_SCH][30];
+    int32_t sFa[SRK_SCH], sFb[SRK_SCH];
+};
+template <typename WT>
+__device__ __forceinline__ void schur_one_landmark(const SrkDims& d, double c, const int64_t* __restrict__ row_ptr,
+                                                   const int32_t* __restrict__ obs_frame, const WT* __restrict__ W,
+                                                   const double* __restrict__ Vg, double* __restrict__ S,
+                                                   double* __restrict__ rhs, int64_t pt, SchurLmScratch& sm)
+{
+    auto& sWa = sm.sWa;
+    auto& sYb = sm.sYb;
+    auto& sFa = sm.sFa;
+    auto& sFb = sm.sFb;
+    double Einv[9], g[3];
+    bool ok = point_block_inverse(Vg, d.Ns, pt, c, Einv, g); // block-uniform
+    if (!ok) return;                                          // :1877-1881 skip the landmark
+    double Eg[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) Eg[m] = Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2];
+    int64_t o0 = row_ptr[pt];
+    int n = (int)(row_ptr[pt + 1] - o0);
+    int nchunks = (n + SRK_SCH - 1) / SRK_SCH;
+    for (int ca = 0; ca < nchunks; ++ca) {
+        int a0 = ca * SRK_SCH;
+        int na = n - a0 < SRK_SCH ? n - a0 : SRK_SCH;
+        __syncthreads();
+        for (int t = threadIdx.x; t < na * 30; t += 256) {
+            int k = t / na, a = t - k * na;
+            sWa[a][k] = W[(int64_t)k * d.Os + o0 + a0 + a];
+        }
+        if (threadIdx.x < na) sFa[threadIdx.x] = obs_frame[o0 + a0 + threadIdx.x];
+        __syncthreads();
+        // rhs += F^T E^-1 g   (:1895-1897)
+        for (int t = threadIdx.x; t < na * 10; t += 256) {
+            int a = t / 10, r = t - a * 10;
+            int64_t row = 10 * (int64_t)sFa[a] + r;
+            if (!srk_is_fixed_var(row, d.comp)) {
+                double v = sWa[a][r] * Eg[0] + sWa[a][10 + r] * Eg[1] + sWa[a][20 + r] * Eg[2];
+                atomicAdd(&rhs[row], v);
+            }
+        }
+        for (int cb = 0; cb <= ca; ++cb) {
+            int b0 = cb * SRK_SCH;
+            int nb = n - b0 < SRK_SCH ? n - b0 : SRK_SCH;
+            __syncthreads();
+            for (int t = threadIdx.x; t < nb * 10; t += 256) {
+                int fv = t / nb, b = t - fv * nb;
+                int64_t ob = o0 + b0 + b;
+                double w0 = W[(int64_t)fv * d.Os + ob], w1 = W[(int64_t)(10 + fv) * d.Os + ob],
+                       w2 = W[(int64_t)(20 + fv) * d.Os + ob];
+                // Y = E^-1 W  (3 x 10)
+                sYb[b][fv] = Einv[0] * w0 + Einv[1] * w1 + Einv[2] * w2;
+                sYb[b][10 + fv] = Einv[3] * w0 + Einv[4] * w1 + Einv[5] * w2;
+                sYb[b][20 + fv] = Einv[6] * w0 + Einv[7] * w1 + Einv[8] * w2;
+            }
+            if (threadIdx.x < nb) sFb[threadIdx.x] = obs_frame[o0 + b0 + threadIdx.x];
+            __syncthreads();
+            int total = na * nb * 100;
+            for (int t = threadIdx.x; t < total; t += 256) {
+                int e = t % 100, pr = t / 100;
+                int b = pr % nb, a = pr / nb;
+                if (ca == cb && b > a) continue; // lower block triangle only (frames ascend inside a landmark)
+                int r = e / 10, cc = e - r * 10;
+                int64_t row = 10 * (int64_t)sFa[a] + r, col = 10 * (int64_t)sFb[b] + cc;
+                if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
+                double v = sWa[a][r] * sYb[b][cc] + sWa[a][10 + r] * sYb[b][10 + cc] + sWa[a][20 + r] * sYb[b][20 + cc];
+                atomicAdd(&S[row * d.ld + col], -v); // S = G - sum F^T E^-1 F  (:1891-1892)
+            }
+        }
+    }
+    __syncthreads(); // the scratch is free for the next landmark
+}
 
 template <typename WT>
 __global__ __launch_bounds__(256) void k_schur(SrkDims d, double c, const int64_t* __restrict__ row_ptr,
@@ -729,69 +839,9 @@ __global__ __launch_bounds__(256) void k_schur(SrkDims d, double c, const int64_
                                                double* __restrict__ rhs, const int32_t* __restrict__ pt_list,
                                                int64_t n_list)
 {
-    __shared__ double sWa[SRK_SCH][30];
-    __shared__ double sYb[SRK_SCH][30];
-    __shared__ int32_t sFa[SRK_SCH], sFb[SRK_SCH];
-    for (int64_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        int64_t pt = pt_list ? pt_list[li] : li;
-        double Einv[9], g[3];
-        bool ok = point_block_inverse(Vg, d.Ns, pt, c, Einv, g); // block-uniform
-        if (!ok) continue;                                        // :1877-1881 skip the landmark
-        double Eg[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) Eg[m] = Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2];
-        int64_t o0 = row_ptr[pt];
-        int n = (int)(row_ptr[pt + 1] - o0);
-        int nchunks = (n + SRK_SCH - 1) / SRK_SCH;
-        for (int ca = 0; ca < nchunks; ++ca) {
-            int a0 = ca * SRK_SCH;
-            int na = n - a0 < SRK_SCH ? n - a0 : SRK_SCH;
-            __syncthreads();
-            for (int t = threadIdx.x; t < na * 30; t += 256) {
-                int k = t / na, a = t - k * na;
-                sWa[a][k] = W[(int64_t)k * d.Os + o0 + a0 + a];
-            }
-            if (threadIdx.x < na) sFa[threadIdx.x] = obs_frame[o0 + a0 + threadIdx.x];
-            __syncthreads();
-            // rhs += F^T E^-1 g   (:1895-1897)
-            for (int t = threadIdx.x; t < na * 10; t += 256) {
-                int a = t / 10, r = t - a * 10;
-                int64_t row = 10 * (int64_t)sFa[a] + r;
-                if (!srk_is_fixed_var(row, d.comp)) {
-                    double v = sWa[a][r] * Eg[0] + sWa[a][10 + r] * Eg[1] + sWa[a][20 + r] * Eg[2];
-                    atomicAdd(&rhs[row], v);
-                }
-            }
-            for (int cb = 0; cb <= ca; ++cb) {
-                int b0 = cb * SRK_SCH;
-                int nb = n - b0 < SRK_SCH ? n - b0 : SRK_SCH;
-                __syncthreads();
-                for (int t = threadIdx.x; t < nb * 10; t += 256) {
-                    int fv = t / nb, b = t - fv * nb;
-                    int64_t ob = o0 + b0 + b;
-                    double w0 = W[(int64_t)fv * d.Os + ob], w1 = W[(int64_t)(10 + fv) * d.Os + ob],
-                           w2 = W[(int64_t)(20 + fv) * d.Os + ob];
-                    // Y = E^-1 W  (3 x 10)
-                    sYb[b][fv] = Einv[0] * w0 + Einv[1] * w1 + Einv[2] * w2;
-                    sYb[b][10 + fv] = Einv[3] * w0 + Einv[4] * w1 + Einv[5] * w2;
-                    sYb[b][20 + fv] = Einv[6] * w0 + Einv[7] * w1 + Einv[8] * w2;
-                }
-                if (threadIdx.x < nb) sFb[threadIdx.x] = obs_frame[o0 + b0 + threadIdx.x];
-                __syncthreads();
-                int total = na * nb * 100;
-                for (int t = threadIdx.x; t < total; t += 256) {
-                    int e = t % 100, pr = t / 100;
-                    int b = pr % nb, a = pr / nb;
-                    if (ca == cb && b > a) continue; // lower block triangle only (frames ascend inside a landmark)
-                    int r = e / 10, cc = e - r * 10;
-                    int64_t row = 10 * (int64_t)sFa[a] + r, col = 10 * (int64_t)sFb[b] + cc;
-                    if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
-                    double v = sWa[a][r] * sYb[b][cc] + sWa[a][10 + r] * sYb[b][10 + cc] + sWa[a][20 + r] * sYb[b][20 + cc];
-                    atomicAdd(&S[row * d.ld + col], -v); // S = G - sum F^T E^-1 F  (:1891-1892)
-                }
-            }
-        }
-    }
+    __shared__ SchurLmScratch sm;
+    for (int64_t li = blockIdx.x; li < n_list; li += gridDim.x)
+        schur_one_landmark<WT>(d, c, row_ptr, obs_frame, W, Vg, S, rhs, pt_list ? pt_list[li] : li, sm);
 }
 
 void srk_launch_schur(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_frame,
@@ -1465,7 +1515,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
-    const int32_t* __restrict__ grp_frames)
+    const int32_t* __restrict__ grp_frames, int32_t* __restrict__ irr /* [0]: count, [1 ..]: landmarks handed back */)
 {
     constexpr int PB = SRK_GRP_PB;             // landmarks of a round
     constexpr int KR = 3 * PB;                 // k rows of a round
@@ -1536,7 +1586,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 dst[j] = rd * WB + (3 * pl + m) * LDW + 10 * a + rr;
             }
         }
-        if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
+        if (tid < np && ragged) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
             double Einv[9], g[3];
             bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
 #pragma unroll
@@ -1544,6 +1594,19 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #pragma unroll
             for (int m = 0; m < 3; ++m)
                 sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
+        }
+        if (tid < np && !ragged) {
+            // uniform runs take the SYRK form: E = L L^T, the helpers stage Z = L^-1 W alone and both MFMA operands read
+            // it (sum W^T E^-1 W = Z^T Z).  sE row: 1/l00 l10 1/l11 l20 l21 1/l22 | L^-1 g.  A skipped landmark (|det| <=
+            // 1e-12) stages zeros; one whose block passes that check but has no positive pivots stages zeros as well and is
+            // handed back (irr) to the per-landmark inverse path, which k_assemble's tail workgroups run.
+            double Lc[6], hh[3];
+            const int st = point_block_cholesky(Vg, d.Ns, p0 + tid, c, Lc, hh);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sE[tid][k] = st == 1 ? Lc[k] : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) sE[tid][6 + m] = st == 1 ? hh[m] : 0.0;
+            if (st == 2) irr[1 + atomicAdd(&irr[0], 1)] = (int32_t)(p0 + tid);
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -1658,6 +1721,39 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (nb < PB)
                 for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = by[3 * nb * LDW + t] = 0;
         };
+        // uniform runs, rounds 0 and 1 (staged raw by the whole workgroup): Z = L^-1 W in place
+        auto z_round = [&](int r, double* bw) {
+            const int pb = r * PB;
+            const int nb = np - pb < PB ? np - pb : PB;
+            if (ypl < nb) {
+                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]);
+                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
+                const double i0 = e01.x, l10 = e01.y, i1 = e23.x, l20 = e23.y, l21 = e45.x, i2 = e45.y;
+                double w[NC][3];
+                int cc[NC];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int col = lane + 64 * i;
+                    cc[i] = col < nf10 ? col : LDW - 1;
+                    const double* wp = bw + 3 * ypl * LDW + cc[i];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) w[i][m] = wp[m * LDW];
+                }
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int col = lane + 64 * i;
+                    double* wp = bw + 3 * ypl * LDW + cc[i];
+                    const double z0 = w[i][0] * i0;
+                    const double z1 = (w[i][1] - l10 * z0) * i1;
+                    const double z2 = (w[i][2] - l20 * z0 - l21 * z1) * i2;
+                    wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
+                    const double rr = z0 * e67.x + z1 * e67.y + z2 * e89.x;
+                    racc[i] += col < nf10 ? rr : 0.0;
+                }
+            }
+            if (nb < PB)
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
+        };
         // Uniform runs (every landmark sees the run's whole frame set), rounds >= 2: W and Y of a round are staged TOGETHER,
         // straight from the registers the global loads landed in.  In-kernel stamps of the two-pass form below (stage W,
         // then read it back and form Y a round later): the helpers -- which only issue while their SIMD's multiplying
@@ -1691,36 +1787,38 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 }
             }
         };
-        auto stage_round2 = [&](int r, double* bw, double* by) {
+        // (round 3: the SYRK form -- the lane forms z = L^-1 w for its columns, a 3 x 3 forward substitution on the registers
+        // it already holds, and stages that ONE array: half the LDS writes of the W + Y form, six multiply-adds instead of nine)
+        auto stage_round2 = [&](int r, double* bw) {
             const int pb = r * PB;
             const int nb = np - pb < PB ? np - pb : PB;
             if (q2 < nq2) {
                 const double2* E2 = reinterpret_cast<const double2*>(sE[pb + pl2]);
-                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
+                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
+                const double i0 = e01.x, l10 = e01.y, i1 = e23.x, l20 = e23.y, l21 = e45.x, i2 = e45.y;
 #pragma unroll
                 for (int b = 0; b < NBT; ++b) {
                     const int i = i02 + 3 * b;
                     if (i < 10) {
-                        const double w0 = pre2[b][0], w1 = pre2[b][1], w2 = pre2[b][2];
+                        const double z0 = pre2[b][0] * i0;
+                        const double z1 = (pre2[b][1] - l10 * z0) * i1;
+                        const double z2 = (pre2[b][2] - l20 * z0 - l21 * z1) * i2;
                         double* wp = bw + dst2 + i;
-                        double* yp = by + dst2 + i;
-                        wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2;
-                        yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
-                        yp[LDW] = e23.y * w0 + e45.x * w1 + e45.y * w2;
-                        yp[2 * LDW] = e67.x * w0 + e67.y * w1 + e89.x * w2;
-                        racc2[b] += w0 * e89.y + w1 * eab.x + w2 * eab.y;
+                        wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
+                        racc2[b] += z0 * e67.x + z1 * e67.y + z2 * e89.x;
                     }
                 }
             }
             // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
             if (nb < PB)
-                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = by[3 * nb * LDW + t] = 0;
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
         };
         load_mask(0);
-        y_round(0, sBuf, sBuf + 3 * WB);
+        if (ragged) y_round(0, sBuf, sBuf + 3 * WB);
+        else z_round(0, sBuf);
         load_mask(1);
         if (!ragged) {
-            if (R > 1) y_round(1, sBuf + WB, sBuf + 4 * WB);
+            if (R > 1) z_round(1, sBuf + WB);
 #pragma unroll
             for (int i = 0; i < NC; ++i) { // the two-pass rounds' share of the rhs: out of the registers before the loop
                 if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
@@ -1735,7 +1833,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         int wi = 2; // W buffer of round r + 2
         if (!ragged) {
             for (int r = 0; r < R; ++r) {
-                if (r + 2 < R) stage_round2(r + 2, sBuf + wi * WB, sBuf + (3 + wi) * WB);
+                if (r + 2 < R) stage_round2(r + 2, sBuf + wi * WB);
 #ifdef SRK_MM_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -1845,7 +1943,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             int wi = 0; // W buffer of round r
             for (int r = 0; r < R; ++r) {
                 const double* bw = sBuf + wi * WB;
-                const double* by = sBuf + (3 + (ragged ? (r & 1) : wi)) * WB; // uniform runs: Y triple-buffered with W
+                const double* by = ragged ? sBuf + (3 + (r & 1)) * WB : bw; // uniform runs: Z^T Z, both operands from Z
                 wi = wi == 2 ? 0 : wi + 1;
 #ifdef SRK_SCH_NOACC
                 if (d.N < 0)
@@ -1862,7 +1960,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             int wi = 0;
             for (int r = 0; r < R; ++r) {
                 const double* bw = sBuf + wi * WB;
-                const double* by = sBuf + (3 + wi) * WB; // (uniform runs: Y triple-buffered with W)
+                const double* by = bw; // uniform runs: Z^T Z, both operands read the one staged array
                 wi = wi == 2 ? 0 : wi + 1;
 #ifdef SRK_SCH_NOACC
                 if (d.N < 0)
@@ -2098,7 +2196,7 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
                               const int32_t* grp_frames, int64_t n_groups, int64_t n_wide, int64_t n_mid,
-                              int fp32_accumulate)
+                              int fp32_accumulate, int32_t* irr)
 {
     if (n_groups <= 0) return;
     // runs over at most SRK_WS_NF frames go to the MFMA kernel, fp64 only (the opt-in fp32 accumulation keeps the packed
@@ -2123,7 +2221,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
     } while (0)
     if (!no_ws && n_wide + n_mid < n_groups) { // runs over at most SRK_WS_NF frames: the MFMA kernel
         if (env_valu) SRK_SCHUR_LAUNCH(k_schur_ws, block, double, );
-        else SRK_SCHUR_LAUNCH(k_schur_mm, dim3(SRK_MM_THREADS), );
+        else if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);
+        else hipLaunchKernelGGL((k_schur_mm<double>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);
     }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread
         if (fp32_accumulate) SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 1, float, );
@@ -2142,9 +2241,23 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
 // sums; fixed variables and padding rows get an identity diagonal (:1780-1823, :1902-1908).
 // `ident`: the identity diagonal of fixed / padding variables (1; 0 on all ranks but one when the assembled systems
 // of several landmark shards are summed afterwards).
-__global__ void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, double* __restrict__ S,
-                           double* __restrict__ rhs, double ident)
+// The last SRK_ASM_TAIL workgroups serve the landmarks k_schur_mm's SYRK form handed back (a point block that passes the
+// determinant check without positive pivots; irr[0] = how many, normally none): the per-landmark inverse path.
+#define SRK_ASM_TAIL 8
+template <typename WT>
+__global__ __launch_bounds__(256) void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, double* __restrict__ S,
+                                                  double* __restrict__ rhs, double ident, const int64_t* __restrict__ row_ptr,
+                                                  const int32_t* __restrict__ obs_frame, const WT* __restrict__ W,
+                                                  const double* __restrict__ Vg, const int32_t* __restrict__ irr)
 {
+    if (blockIdx.x >= gridDim.x - SRK_ASM_TAIL) {
+        const int n = irr ? irr[0] : 0;
+        if (n <= 0) return;
+        __shared__ SchurLmScratch sm;
+        for (int li = (int)(blockIdx.x - (gridDim.x - SRK_ASM_TAIL)); li < n; li += SRK_ASM_TAIL)
+            schur_one_landmark<WT>(d, c, row_ptr, obs_frame, W, Vg, S, rhs, irr[1 + li], sm);
+        return;
+    }
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t nblk = (int64_t)d.M * 110;
     if (t < nblk) {
@@ -2178,10 +2291,15 @@ __global__ void k_assemble(SrkDims d, double c, const double* __restrict__ Ug, d
     }
 }
 
-void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs, double ident)
+void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs, double ident,
+                         const int64_t* row_ptr, const int32_t* obs_frame, const double* W, const double* Vg, const int32_t* irr)
 {
     int64_t n = (int64_t)d.M * 110 + (d.ld - 10 * (int64_t)d.M);
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, c, Ug, S, rhs, ident);
+    const dim3 grid((unsigned)((n + 255) / 256 + SRK_ASM_TAIL));
+    if (d.w_f32)
+        hipLaunchKernelGGL(k_assemble<float>, grid, dim3(256), 0, s, d, c, Ug, S, rhs, ident, row_ptr, obs_frame,
+                           reinterpret_cast<const float*>(W), Vg, irr);
+    else hipLaunchKernelGGL(k_assemble<double>, grid, dim3(256), 0, s, d, c, Ug, S, rhs, ident, row_ptr, obs_frame, W, Vg, irr);
 }
 
 // mirror the lower triangle into the upper one (downloads / exchange of the full matrix)
@@ -2524,18 +2642,20 @@ void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const d
 // (multiple of 256) that can be non-zero in the 128-row tile row t; Cholesky fill stays inside that skyline.
 // zero / pack / unpack touch only rows' segments [env_col[t], 128 (t + 1)) -- the lower triangle inside the skyline.
 __global__ __launch_bounds__(256) void k_env_zero(int64_t ld, const int64_t* __restrict__ env_col, double* __restrict__ S,
-                                                  double* __restrict__ rhs /* zeroed too when given */)
+                                                  double* __restrict__ rhs /* zeroed too when given */,
+                                                  int32_t* __restrict__ irr /* k_schur_mm's hand-back counter, cleared too */)
 {
     int64_t t = blockIdx.y;
+    if (irr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) irr[0] = 0;
     int64_t c0 = env_col[t], c1 = 128 * (t + 1);
     int64_t row = 128 * t + blockIdx.x;
     if (rhs && threadIdx.x == 0) rhs[row] = 0.0;
     double* p = S + row * ld;
     for (int64_t c = c0 + 2 * threadIdx.x; c < c1; c += 512) *reinterpret_cast<double2*>(p + c) = make_double2(0.0, 0.0);
 }
-void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S, double* rhs)
+void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S, double* rhs, int32_t* irr)
 {
-    hipLaunchKernelGGL(k_env_zero, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, S, rhs);
+    hipLaunchKernelGGL(k_env_zero, dim3(128, (unsigned)(ld / 128)), dim3(256), 0, s, ld, env_col, S, rhs, irr);
 }
 
 // pack: out[env_off[t] + r * w + (c - c0)] = S[row][c], w = c1 - c0 ; dir = 0 pack, 1 unpack

@@ -72,7 +72,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               const int32_t* grp_frames /* [n_groups][SRK_GRP_MAXNF_HOST] */, int64_t n_groups,
                               int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */,
                               int64_t n_mid /* runs with SRK_WS_NF_HOST < frames <= SRK_GRP_NF1_HOST */,
-                              int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */);
+                              int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */,
+                              int32_t* irr /* [0] count + list of landmarks k_schur_mm hands back to the inverse path */);
 // tracks longer than SRK_GRP_MAXNF_HOST frames: runs of <= SRK_LONG_PTS_HOST landmarks over a frame set of
 // <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur
 #define SRK_LONG_PTS_HOST 128
@@ -85,7 +86,9 @@ void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const doub
                            const int32_t* run_frames /* [run][SRK_LONG_MAXNF_HOST] the run's frame set, ascending */,
                            const int64_t* run_obs_off, const int32_t* run_obs /* [off + landmark * 8 ceil(nf / 8) + slot]: observation or -1 */);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
-                         double ident /* diagonal of fixed / padding variables */);
+                         double ident /* diagonal of fixed / padding variables */, const int64_t* row_ptr,
+                         const int32_t* obs_frame, const double* W, const double* Vg,
+                         const int32_t* irr /* landmarks handed back by k_schur_mm: served by the tail workgroups */);
 void srk_launch_backsub(hipStream_t s, const SrkDims& d, double c, const int32_t* obs_frame, const int32_t* obs_pt,
                         const double* W, const double* Vg, const double* dc, double* acc, const double* pts,
                         double* pts_trial, double* dx);
@@ -104,7 +107,8 @@ void srk_launch_error_score(hipStream_t s, int64_t O, const double* pts, const d
 void srk_launch_expand_ug(hipStream_t s, int32_t M, const double* Ug, double* U_full, double* g_full);
 void srk_launch_symmetrize(hipStream_t s, int64_t n, int64_t ld, double* S);
 
-void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S, double* rhs /* zeroed too, or null */);
+void srk_launch_env_zero(hipStream_t s, int64_t ld, const int64_t* env_col, double* S, double* rhs /* zeroed too, or null */,
+                         int32_t* irr = nullptr /* hand-back counter of k_schur_mm, cleared too */);
 void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, const int64_t* env_off, double* S,
                          double* packed, int dir);
 void srk_launch_band_pack(hipStream_t s, int64_t ld, const int64_t* band_col, const int64_t* band_off, double* S,

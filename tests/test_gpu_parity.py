@@ -779,6 +779,62 @@ def test_c5_nested_dissection_agrees_with_single_chain(gpu):
     assert rel_err(res[2][4], res[1][4]) < 1e-8
 
 
+def test_c5_full_size_blocks_sampled_system_rows_and_corrections_vs_oracle(orc, gpu):
+    """BASELINE config 5 (4000 cams / 1M pts / 20M obs, n = 39993) at full size against the oracle: reprojection error,
+    gradient and every point / frame / point-frame block (rel 1e-12, gradient 1e-10, and on the scale of each variable
+    class), the right-hand side of the reduced camera system, its rows for 25 frames spread over the sequence (250 rows
+    of 39993 entries: the oracle's skyline variant returns selected rows, so neither side needs the 12.8 GB dense
+    matrix), and the corrections of the whole step against the oracle's skyline Cholesky (rel 1e-8).  The oracle runs its
+    OpenMP variant (bit-identical to one thread, tests/test_oracle_skyline.py)."""
+    import os
+    spec = sa.CONFIGS["C5_4kcam_1Mpt"]
+    sc = sa.config_scene("C5_4kcam_1Mpt")
+    assert (sc.M, sc.N, sc.O) == (4000, 1000000, 20000000)
+    so = _orc_scene(orc, sc)
+    ok, _ = orc.normalize(so)
+    assert ok and gpu.upload(spec.f0, sc)
+    M, c = sc.M, 1e-4
+    orc.set_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    try:
+        eo, seen_o = orc.reproj_error(spec.f0, so)
+        eg, seen_g = gpu.phase_error()
+        assert seen_g == seen_o == sc.O and eg == pytest.approx(eo, rel=1e-12)
+        gradE, V, U, W = orc.derivatives(spec.f0, so)
+        gpu.phase_derivatives()
+        Vg_, Ug_, gg_ = (gpu.buffer(B.BUF_POINT_BLOCKS).reshape(-1, 3, 3), gpu.buffer(B.BUF_FRAME_BLOCKS).reshape(-1, 10, 10),
+                         gpu.buffer(B.BUF_GRAD))
+        assert rel_err(Vg_, V) < 1e-12 and rel_err(Ug_, U) < 1e-12 and rel_err(gg_, gradE) < 1e-10
+        Wg = gpu.buffer(B.BUF_POINT_FRAME).reshape(-1, 3, 10)
+        assert rel_err(Wg, W) < 1e-12
+        dU = _check_blocks_by_class(Vg_, V, Ug_, U, Wg, W, gg_, gradE, eo)
+        del Wg, Vg_
+        red = _reduced_index(M)
+        keep = red >= 0
+        frames = np.unique(np.linspace(2, M - 1, 25).astype(np.int64))
+        full_rows = (10 * frames[:, None] + np.arange(10)[None, :]).reshape(-1)
+        ok_o, corr_o, rows_o, rhs_o = orc.two_phase_skyline(so, gradE, V, U, W, c, sel_rows=red[full_rows], want_rhs=True)
+        assert ok_o
+    finally:
+        orc.set_threads(1)
+    del W
+    gpu.phase_schur(c)
+    rg = gpu.buffer(B.BUF_RCS_RHS)
+    assert rel_err(rg[keep], rhs_o) < 1e-10
+    rows_g = gpu.rcs_rows(full_rows)[:, keep]
+    scale = float(np.abs(rows_o).max())     # (the sampled rows hold pose-variable diagonals: the system's largest entries)
+    assert float(np.abs(rows_g - rows_o).max()) < 1e-10 * scale
+    dk = dU[keep]
+    assert float((np.abs(rows_g - rows_o) / (dU[full_rows][:, None] * dk[None, :])).max()) < 1e-10
+    gs = 2.0 * np.sqrt(eo)
+    assert float((np.abs(rg[keep] - rhs_o) / (dk * gs)).max()) < 1e-10
+    assert gpu.phase_solve()
+    gpu.phase_backsub(c)
+    corr_g = gpu.buffer(B.BUF_CORRECTIONS)
+    assert rel_err(corr_g[3 * sc.N:], corr_o[3 * sc.N:]) < 1e-8
+    assert rel_err(corr_g[:3 * sc.N], corr_o[:3 * sc.N]) < 1e-8
+    gpu.upload(SCENES["tiny"].f0, sa.generate_scene(SCENES["tiny"]))  # release the 13 GB system
+
+
 # ------------------------------------------------------------------ sharded path, world size 1 on the GPU
 
 def test_native_rccl_exchange_world_size_1(orc):
