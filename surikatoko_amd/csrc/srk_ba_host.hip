@@ -277,6 +277,7 @@ void srk_ba_destroy(srk_ba* h)
     for (auto& a : h->att) {
         for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
+        srk_chol_sync_free(&a.sync);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
     }

@@ -1832,16 +1832,23 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #endif
         int wi = 2; // W buffer of round r + 2
         if (!ragged) {
-            for (int r = 0; r < R; ++r) {
-                if (r + 2 < R) stage_round2(r + 2, sBuf + wi * WB);
+            // (round 3) DOUBLE rounds: with Z alone in LDS the arena holds six rounds, so a barrier closes TWO rounds of four
+            // landmarks (six K = 4 steps of the multiplying waves) -- half the barriers, half the pipeline ramps.  Rounds r,
+            // r + 1 are multiplied while the helpers stage r + 2 (loads issued half a double round ago) and r + 3 (loads
+            // issued at the start of this one); round u lives in buffer u % 6.
+            for (int r = 0; r < R; r += 2) {
+                if (r + 2 < R) stage_round2(r + 2, sBuf + ((r + 2) % 6) * WB);
 #ifdef SRK_MM_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
                 MM_ACC(64 * SRK_MM_CW, 10, tacc);
-                if (r + 3 < R) load_round2(r + 3);
+                if (r + 3 < R) {
+                    load_round2(r + 3);
+                    stage_round2(r + 3, sBuf + ((r + 3) % 6) * WB);
+                }
+                if (r + 4 < R) load_round2(r + 4);
                 MM_ACC(64 * SRK_MM_CW, 11, tacc);
-                wi = wi == 2 ? 0 : wi + 1;
-                lds_barrier(); // the products of round r; W and Y of round r + 2 are visible
+                lds_barrier(); // the products of rounds r, r + 1; Z of rounds r + 2, r + 3 are visible
                 MM_ACC(64 * SRK_MM_CW, 12, tacc);
             }
 #pragma unroll
@@ -1940,10 +1947,27 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         };
         const int pat = __builtin_amdgcn_readfirstlane(100 * pattern(0) + pattern(4));
         auto rounds = [&](auto p0, auto p1) {
+            if (!ragged) { // uniform runs: double rounds of Z^T Z (see the helpers), round u in buffer u % 6
+                for (int r = 0; r < R; r += 2) {
+                    const double* bw = sBuf + (r % 6) * WB;
+#ifdef SRK_SCH_NOACC
+                    if (d.N < 0)
+#endif
+                    {
+                        schur_mm_steps<SRK_MM_SLOTS, decltype(p0)::value, decltype(p1)::value>(acc, bw, bw, ta, tb, lbase);
+                        if (r + 1 < R)
+                            schur_mm_steps<SRK_MM_SLOTS, decltype(p0)::value, decltype(p1)::value>(acc, bw + WB, bw + WB, ta, tb, lbase);
+                    }
+                    MM_ACC(0, 6, tacc);
+                    lds_barrier();
+                    MM_ACC(0, 7, tacc);
+                }
+                return;
+            }
             int wi = 0; // W buffer of round r
             for (int r = 0; r < R; ++r) {
                 const double* bw = sBuf + wi * WB;
-                const double* by = ragged ? sBuf + (3 + (r & 1)) * WB : bw; // uniform runs: Z^T Z, both operands from Z
+                const double* by = sBuf + (3 + (r & 1)) * WB;
                 wi = wi == 2 ? 0 : wi + 1;
 #ifdef SRK_SCH_NOACC
                 if (d.N < 0)
@@ -1957,15 +1981,15 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             }
         };
         if (blk) {
-            int wi = 0;
-            for (int r = 0; r < R; ++r) {
-                const double* bw = sBuf + wi * WB;
-                const double* by = bw; // uniform runs: Z^T Z, both operands read the one staged array
-                wi = wi == 2 ? 0 : wi + 1;
+            for (int r = 0; r < R; r += 2) { // uniform runs: double rounds (see the helpers), round u in buffer u % 6
+                const double* bw = sBuf + (r % 6) * WB; // Z^T Z: both operands read the one staged array
 #ifdef SRK_SCH_NOACC
                 if (d.N < 0)
 #endif
-                schur_mm_steps_blk(acc, bw, by, ta, tb, lbase);
+                {
+                    schur_mm_steps_blk(acc, bw, bw, ta, tb, lbase);
+                    if (r + 1 < R) schur_mm_steps_blk(acc, bw + WB, bw + WB, ta, tb, lbase);
+                }
                 MM_ACC(0, 6, tacc);
 #ifndef SRK_MM_NO_ROUND_BARRIER
                 lds_barrier();
