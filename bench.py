@@ -340,7 +340,10 @@ def main():
 
             id1 = new_id()
             native_step("srk_ba_rccl_init", lambda: ba.rccl_init(id1, rank, world))
-            exchange = "native RCCL on the library's streams"
+            sched = os.environ.get("SRK_MULTI_SCHEDULE", "dp")
+            exchange = ("native RCCL, damping-parallel schedule: band k reduced to rank k, corrections broadcast, one all-reduce of "
+                        "the status words; one communicator on the library's collective stream") if sched != "allreduce" else \
+                       "native RCCL all-reduce of the band on the attempt's stream (round-2 schedule)"
         else:
             from surikatoko_amd.dist import make_allreduce_hook
             ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
@@ -618,7 +621,8 @@ def main():
                           "step": "one accepted outer LM iteration with its rejected attempts, one continuing run",
                           "parallelism": out["config"]["parallelism"], "exchange": exchange, "rcs_solver": args.rcs,
                           "rcs_chunks": rcs_chunks,
-                          "lm_attempts": "sequential" if args.sequential_attempts else "speculative pairs"}
+                          "lm_attempts": ("sequential" if args.sequential_attempts else
+                                          ("speculative pairs" if world == 1 else f"{min(3, world)} damping factors a round, one per rank"))}
         line.update({"iterations_done": iterations, "attempts_per_s": out["attempts_per_s"],
                      "attempts_per_iteration": out["attempts_per_iteration"], "solver_sync_timeouts": timeouts,
                      "roofline": rl,

@@ -34,6 +34,7 @@ struct DevBuf {
 
 } // namespace
 
+#define SRK_SLOTS 3 // attempt slots: two on one GPU (speculative pairs), up to three with several ranks (one damping factor each)
 struct srk_ba {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -49,7 +50,7 @@ struct srk_ba {
     bool normalized_on_upload = false;
 
     // device buffers
-    DevBuf pts[3], camR[3], camT[3], K, cam[3]; // the current scene + one trial scene per attempt slot
+    DevBuf pts[SRK_SLOTS + 1], camR[SRK_SLOTS + 1], camT[SRK_SLOTS + 1], K, cam[SRK_SLOTS + 1]; // the current scene + one trial scene per attempt slot
     DevBuf pts0, camR0, camT0; // copy of the uploaded (normalised) scene for srk_ba_reset_scene
     DevBuf row_ptr, obs_frame, obs_pt, obs_uv, col_ptr, fobs_pt, fobs_uv;
     DevBuf W, Vg, Ug, scratch;
@@ -61,6 +62,7 @@ struct srk_ba {
     int64_t n_long_items = 0, n_long_runs = 0;
     DevBuf sc_pts, sc_R, sc_T, sc_K, sc_cam, sc_frame, sc_pt, sc_uv, sc_partial, sc_out; // standalone scoring path
     int64_t n_groups = 0, n_groups_wide = 0, n_groups_mid = 0, n_generic = 0;
+    int64_t n_mm_uniform = 0, n_mm_ragged = 0; // runs the MFMA kernel takes (<= SRK_WS_NF_HOST frames), by kind
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // run-based Jacobian kernel (k_jac_runs): tasks = pieces of runs of landmarks with identical frame lists
     DevBuf jr_first, jr_count, jr_jmin;
@@ -79,7 +81,7 @@ struct srk_ba {
     // corrections, the trial scene, the status words, and the stream it runs on.  Two slots let the loop run the next
     // damping factor speculatively beside the current one (the solve is a latency chain that leaves the chip idle).
     struct Attempt {
-        DevBuf S, rhs, wy, dc, acc, dx, err_partial, err_out, info, dinv, packed, sync_flags;
+        DevBuf S, rhs, wy, dc, acc, dx, err_partial, info, dinv, packed, sync_flags;
         DevBuf irr; // [0] count + landmarks the SYRK form of k_schur_mm hands back to the per-landmark inverse path
         SrkChunkPlan plan;
         SrkCholSync sync;            // in-launch hand-offs of the fused outer-step kernel (srk_chol.hip: k_step256)
@@ -90,10 +92,12 @@ struct srk_ba {
         double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        hipEvent_t ev_a = nullptr, ev_b = nullptr; // cross-stream hand-offs of the damping-parallel schedule
+        double* err_dst = nullptr;   // {error, solver info, point-update info} of this slot: 8 doubles inside srk_ba::status_all
         int trial = 1;               // index of this slot's trial scene buffers
         bool allocated = false;
     };
-    Attempt att[2];
+    Attempt att[SRK_SLOTS];
     Attempt* A = &att[0]; // the slot the phase functions work on (select_attempt)
     hipStream_t main_stream = nullptr; // = att[0].stream
     hipEvent_t ev_jac = nullptr;       // derivatives done (the second slot's stream waits for it)
@@ -114,6 +118,16 @@ struct srk_ba {
     // host) pairs stay on as well when spec_multi allows: the callback serialises the exchanges on the host.
     ncclComm_t comm2 = nullptr;
     bool spec_multi = true; // SRK_MULTI_SPECULATION=0: one attempt at a time with several ranks
+    // Damping-parallel schedule (world >= 2): an iteration's attempts c, 10c, 100c are built by every rank on its
+    // shard, band k is REDUCED to rank k, rank k solves factor k and broadcasts its corrections, every rank scores all of
+    // them.  All collectives of that schedule go through ONE communicator on ONE stream (comm_stream) in one program order.
+    bool dp_schedule = true;          // SRK_MULTI_SCHEDULE=allreduce: the round-2 schedule (all-reduce, redundant solves)
+    bool dp_force = false;            // SRK_MULTI_SCHEDULE=dp_force: the schedule at world size 1 as well (three slots, every
+                                      // collective issued; all one GPU can rehearse of the native path)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_comm = nullptr;
+    DevBuf status_all;                // [SRK_SLOTS][8] doubles: the slots' {error, solver info, point-update info}
+    double* dp_back = nullptr;        // pinned copy of status_all
     int64_t seen_global = -1; // observation count over all ranks of the uploaded scene (-1 = not yet exchanged)
 
     // timing
@@ -142,8 +156,13 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    bool rooted = false; // Reduce / Broadcast / GroupStart / GroupEnd resolved (else they are emulated by all-reduces)
 };
 RcclApi& rccl()
 {
@@ -158,6 +177,11 @@ RcclApi& rccl()
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.lib, "ncclAllReduce"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.Reduce = reinterpret_cast<decltype(a.Reduce)>(dlsym(a.lib, "ncclReduce"));
+        a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(a.lib, "ncclBroadcast"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+        a.rooted = a.Reduce && a.Broadcast && a.GroupStart && a.GroupEnd;
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
         return a;
     }();
@@ -234,14 +258,27 @@ srk_ba* srk_ba_create(int device_id)
     h->main_stream = h->stream;
     if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = e[0] != '0'; // development: the unfused launch sequence
     if (const char* e = getenv("SRK_MULTI_SPECULATION")) h->spec_multi = e[0] != '0';
+    if (const char* e = getenv("SRK_MULTI_SCHEDULE")) {
+        h->dp_schedule = std::strcmp(e, "allreduce") != 0;
+        h->dp_force = std::strcmp(e, "dp_force") == 0;
+    }
     h->att[0].stream = h->stream;
-    h->att[0].trial = 1;
-    h->att[1].trial = 2;
-    bool ok = hipStreamCreateWithFlags(&h->att[1].stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&h->ev_jac, hipEventDisableTiming) == hipSuccess;
-    for (auto& a : h->att)
+    bool ok = hipEventCreateWithFlags(&h->ev_jac, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&h->dp_back), 64 * SRK_SLOTS, hipHostMallocDefault) == hipSuccess &&
+              hipMalloc(&h->status_all.p, 64 * SRK_SLOTS) == hipSuccess;
+    if (ok) h->status_all.bytes = 64 * SRK_SLOTS, ok = hipMemset(h->status_all.p, 0, 64 * SRK_SLOTS) == hipSuccess;
+    for (int sl = 0; sl < SRK_SLOTS; ++sl) {
+        auto& a = h->att[sl];
+        a.trial = sl + 1;
+        a.err_dst = ok ? P<double>(h->status_all) + 8 * sl : nullptr;
+        if (sl > 0) ok = ok && hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&a.done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&a.ev_a, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&a.ev_b, hipEventDisableTiming) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void**>(&a.host_back), 64, hipHostMallocDefault) == hipSuccess;
+    }
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
         delete h;
@@ -262,12 +299,17 @@ void srk_ba_destroy(srk_ba* h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->att[1].stream) hipStreamSynchronize(h->att[1].stream);
+    for (int sl = 1; sl < SRK_SLOTS; ++sl)
+        if (h->att[sl].stream) hipStreamSynchronize(h->att[sl].stream);
+    if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
     if (h->comm2) rccl().CommDestroy(h->comm2); // the second slot's communicator is always owned by the handle
     if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
     h->comm = h->comm2 = nullptr;
-    DevBuf* all[] = { &h->pts[0], &h->pts[1], &h->pts[2], &h->camR[0], &h->camR[1], &h->camR[2], &h->camT[0], &h->camT[1],
-                      &h->camT[2], &h->K, &h->cam[0], &h->cam[1], &h->cam[2], &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
+    for (int w = 0; w < SRK_SLOTS + 1; ++w)
+        for (DevBuf* b : { &h->pts[w], &h->camR[w], &h->camT[w], &h->cam[w] }) dev_free(*b);
+    dev_free(h->status_all);
+    if (h->dp_back) hipHostFree(h->dp_back);
+    DevBuf* all[] = { &h->K, &h->pts0, &h->camR0, &h->camT0, &h->row_ptr,
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
                       &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off,
@@ -275,11 +317,13 @@ void srk_ba_destroy(srk_ba* h)
                       &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
-        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.err_out, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr }) dev_free(*b);
+        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
         srk_chol_sync_free(&a.sync);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
+        if (a.ev_a) hipEventDestroy(a.ev_a);
+        if (a.ev_b) hipEventDestroy(a.ev_b);
     }
     for (DevBuf* b : { &h->sc_pts, &h->sc_R, &h->sc_T, &h->sc_K, &h->sc_cam, &h->sc_frame, &h->sc_pt, &h->sc_uv, &h->sc_partial, &h->sc_out })
         dev_free(*b);
@@ -287,7 +331,10 @@ void srk_ba_destroy(srk_ba* h)
         if (e) hipEventDestroy(e);
     for (auto& e : h->chol_ev) hipEventDestroy(e);
     if (h->ev_jac) hipEventDestroy(h->ev_jac);
-    if (h->att[1].stream) hipStreamDestroy(h->att[1].stream);
+    if (h->ev_comm) hipEventDestroy(h->ev_comm);
+    if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+    for (int sl = 1; sl < SRK_SLOTS; ++sl)
+        if (h->att[sl].stream) hipStreamDestroy(h->att[sl].stream);
     if (h->own_stream && h->main_stream) hipStreamDestroy(h->main_stream);
     delete h;
 }
@@ -327,7 +374,9 @@ int srk_ba_set_allreduce(srk_ba* h, srk_allreduce_fn fn, void* ctx, int rank, in
     if (h->comm || h->comm2) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
-        if (h->att[1].stream) hipStreamSynchronize(h->att[1].stream);
+        for (int sl = 1; sl < SRK_SLOTS; ++sl)
+            if (h->att[sl].stream) hipStreamSynchronize(h->att[sl].stream);
+        if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
         if (h->comm2) rccl().CommDestroy(h->comm2);
         if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
         h->comm = h->comm2 = nullptr;
@@ -688,7 +737,7 @@ static int build_envelope(srk_ba* h)
         HIPCHK(h, hipMemcpyAsync(h->band_off.p, bo.data(), (size_t)(8 * (d.ld + 1)), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream)); // bc / bo are locals
     }
-    for (int sl = 0; sl < 2; ++sl) { // every allocated attempt slot: its own zeroed system and solver plan
+    for (int sl = 0; sl < SRK_SLOTS; ++sl) { // every allocated attempt slot: its own zeroed system and solver plan
         select_attempt(h, 0);
         if (!h->att[sl].allocated) continue;
         HIPCHK(h, hipMemsetAsync(h->att[sl].S.p, 0, (size_t)(8 * d.ld * d.ld), h->stream)); // outside the skyline stays 0
@@ -871,6 +920,11 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     h->n_groups = (int64_t)grp_first.size();
     h->n_groups_wide = n_wide;
     h->n_groups_mid = n_mid;
+    h->n_mm_uniform = h->n_mm_ragged = 0;
+    for (int32_t v : grp_nf) {
+        if (v > 0 && v <= SRK_WS_NF_HOST) ++h->n_mm_uniform;
+        if (v < 0 && -v <= SRK_WS_NF_HOST) ++h->n_mm_ragged;
+    }
     h->n_generic = (int64_t)gen_list.size();
     SrkDims d{};
     d.N = N;
@@ -984,7 +1038,12 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         int _r = dev_alloc(h, (buf), (size_t)(bytes)); \
         if (_r != SRK_OK) return _r;                   \
     } while (0)
-    for (int w = 0; w < 3; ++w) {
+    // several ranks, damping-parallel schedule: one slot per damping factor of a round (at most three)
+    const bool multi_upload = h->allreduce || h->comm;
+    const int n_slots = (multi_upload && h->dp_schedule && (h->world >= 2 || h->dp_force))
+                            ? (h->dp_force ? SRK_SLOTS : std::min(SRK_SLOTS, h->world)) : (h->speculate ? 2 : 1);
+    for (int w = 0; w < SRK_SLOTS + 1; ++w) {
+        if (w > n_slots) continue;
         ALLOC(h->pts[w], 24 * N);
         ALLOC(h->camR[w], 72 * (int64_t)M);
         ALLOC(h->camT[w], 24 * (int64_t)M);
@@ -1001,12 +1060,11 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->col_ptr, 8 * ((int64_t)M + 1));
     ALLOC(h->fobs_pt, 4 * O);
     ALLOC(h->fobs_uv, 16 * O);
-    ALLOC(h->W, (d.w_f32 ? 4 : 8) * 30 * d.Os);
+    ALLOC(h->W, d.w_f32 ? 4 * 30 * d.Os : 8 * SRK_WF_PLANES * d.Os); // f32: the 30 products; fp64: their 21 rank-2 factors
     ALLOC(h->Vg, 8 * 9 * d.Ns);
     ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
     select_attempt(h, 0);
-    const int n_slots = h->speculate ? 2 : 1;
-    for (int sl = 0; sl < 2; ++sl) {
+    for (int sl = 0; sl < SRK_SLOTS; ++sl) {
         srk_ba::Attempt& a = h->att[sl];
         a.allocated = sl < n_slots;
         if (!a.allocated) continue;
@@ -1017,7 +1075,6 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         ALLOC(a.acc, 8 * 3 * d.Ns + 64);
         ALLOC(a.dx, 24 * N);
         ALLOC(a.err_partial, 8 * std::max<int64_t>(1024, srk_error_partials_staged(d)));
-        ALLOC(a.err_out, 64);
         ALLOC(a.info, 64);
         ALLOC(a.dinv, 8 * 64 * d.ld);
         ALLOC(a.irr, 4 * (N + 2));
@@ -1096,8 +1153,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         HIPCHK(h, hipMemsetAsync(a.dx.p, 0, 24 * N > 0 ? 24 * N : 8, s));
     }
     h->cur = 0;
-    h->att[0].trial = 1;
-    h->att[1].trial = 2;
+    for (int sl = 0; sl < SRK_SLOTS; ++sl) h->att[sl].trial = sl + 1;
     rc = compute_cam_packs(h, 0);
     if (rc != SRK_OK) return rc;
     HIPCHK(h, hipStreamSynchronize(s)); // host staging vectors go out of scope
@@ -1148,14 +1204,13 @@ extern "C" int srk_ba_reset_scene(srk_ba* h)
     HIPCHK(h, hipSetDevice(h->device));
     select_attempt(h, 0);
     hipStream_t s = h->stream;
-    HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // a speculative attempt may still read the current scene
+    for (int sl = 1; sl < SRK_SLOTS; ++sl) HIPCHK(h, hipStreamSynchronize(h->att[sl].stream)); // a speculative attempt may still read the current scene
     {
         int rcp = clear_poison(h);
         if (rcp != SRK_OK) return rcp;
     }
     h->cur = 0;
-    h->att[0].trial = 1;
-    h->att[1].trial = 2;
+    for (int sl = 0; sl < SRK_SLOTS; ++sl) h->att[sl].trial = sl + 1;
     if (h->d.N > 0) HIPCHK(h, hipMemcpyAsync(h->pts[0].p, h->pts0.p, 24 * h->d.N, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->camR[0].p, h->camR0.p, 72 * (int64_t)h->d.M, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->camT[0].p, h->camT0.p, 24 * (int64_t)h->d.M, hipMemcpyDeviceToDevice, s));
@@ -1203,22 +1258,76 @@ static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
     return SRK_OK;
 }
 
+// ---- collectives of the damping-parallel schedule (world >= 2).  A group = the same operation for the slots k = 0 .. G-1
+// (root of slot k: k % world), issued by every rank in the same program order.  Natively: ONE communicator on ONE stream
+// (comm_stream) -- the group waits for each slot's producer stream, runs as one ncclGroup (the rooted operations of
+// different roots share the links), and each slot's stream waits for it; nothing waits on the host.  With the callback
+// (gloo rehearsals, a caller's own transport) only a sum is available: a reduce is an all-reduce whose result the other
+// ranks ignore, a broadcast an all-reduce of a buffer the other ranks zeroed; the callback blocks the host.
+enum { SRK_COLL_ALLREDUCE = 0, SRK_COLL_REDUCE = 1, SRK_COLL_BCAST = 2 };
+static int coll_group(srk_ba* h, int op, int G, double* const* ptrs, const int64_t* counts)
+{
+    if (h->comm) {
+        for (int k = 0; k < G; ++k) {
+            HIPCHK(h, hipEventRecord(h->att[k].ev_a, h->att[k].stream));
+            HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->att[k].ev_a, 0));
+        }
+        const bool rooted = rccl().rooted && op != SRK_COLL_ALLREDUCE;
+        if (!rooted && op == SRK_COLL_BCAST)
+            for (int k = 0; k < G; ++k)
+                if (h->rank != k % h->world) HIPCHK(h, hipMemsetAsync(ptrs[k], 0, (size_t)(8 * counts[k]), h->comm_stream));
+        ncclResult_t r = ncclSuccess;
+        if (rooted) r = rccl().GroupStart();
+        for (int k = 0; k < G && r == ncclSuccess; ++k) {
+            const int root = k % h->world;
+            if (rooted && op == SRK_COLL_REDUCE)
+                r = rccl().Reduce(ptrs[k], ptrs[k], (size_t)counts[k], ncclDouble, ncclSum, root, h->comm, h->comm_stream);
+            else if (rooted && op == SRK_COLL_BCAST)
+                r = rccl().Broadcast(ptrs[k], ptrs[k], (size_t)counts[k], ncclDouble, root, h->comm, h->comm_stream);
+            else
+                r = rccl().AllReduce(ptrs[k], ptrs[k], (size_t)counts[k], ncclDouble, ncclSum, h->comm, h->comm_stream);
+        }
+        if (rooted) {
+            ncclResult_t r2 = rccl().GroupEnd();
+            if (r == ncclSuccess) r = r2;
+        }
+        if (r != ncclSuccess) {
+            h->last_error = std::string("RCCL collective: ") + rccl().GetErrorString(r);
+            return SRK_E_DEVICE;
+        }
+        HIPCHK(h, hipEventRecord(h->ev_comm, h->comm_stream));
+        for (int k = 0; k < G; ++k) HIPCHK(h, hipStreamWaitEvent(h->att[k].stream, h->ev_comm, 0));
+        return SRK_OK;
+    }
+    if (!h->allreduce) return SRK_OK;
+    for (int k = 0; k < G; ++k) {
+        hipStream_t st = h->att[k].stream;
+        if (op == SRK_COLL_BCAST && h->rank != k % h->world) HIPCHK(h, hipMemsetAsync(ptrs[k], 0, (size_t)(8 * counts[k]), st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (h->allreduce(h->allreduce_ctx, ptrs[k], counts[k]) != 0) {
+            h->last_error = "allreduce hook failed";
+            return SRK_E_DEVICE;
+        }
+    }
+    return SRK_OK;
+}
+
 // with_status: {solver info, point-update finite flag (lives behind acc)} are packed next to the error scalar and
 // summed over the ranks with it, so every rank takes the same accept / reject decision
-static int phase_error(srk_ba* h, int which, double* err_host, bool with_status = false)
+static int phase_error(srk_ba* h, int which, double* err_host, bool with_status = false, bool no_exchange = false)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
     int32_t np = srk_error_partials(d);
     srk_launch_error(s, d, P<double>(h->pts[which]), P<double>(h->cam[which]), P<int32_t>(h->obs_frame),
-                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->A->err_partial), np, P<double>(h->A->err_out),
+                     P<int32_t>(h->obs_pt), P<double>(h->obs_uv), P<double>(h->A->err_partial), np, h->A->err_dst,
                      h->jac_fused ? P<int32_t>(h->wg_jmin) : nullptr, with_status ? P<int>(h->A->info) : nullptr,
                      with_status ? reinterpret_cast<int*>(reinterpret_cast<char*>(h->A->acc.p) + 8 * 3 * d.Ns) : nullptr);
     HIPCHK(h, hipGetLastError());
-    int rc = exchange(h, P<double>(h->A->err_out), with_status ? 3 : 1);
+    int rc = no_exchange ? SRK_OK : exchange(h, h->A->err_dst, with_status ? 3 : 1);
     if (rc != SRK_OK) return rc;
     if (err_host) {
-        HIPCHK(h, hipMemcpyAsync(err_host, h->A->err_out.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(err_host, h->A->err_dst, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
     }
     return SRK_OK;
@@ -1254,7 +1363,31 @@ static int phase_derivatives(srk_ba* h)
     return SRK_OK;
 }
 
-static int phase_schur(srk_ba* h, double c)
+static int phase_schur(srk_ba* h, double c, bool local_only = false);
+// the reduced camera system of this rank's landmarks, packed for an exchange: band + right-hand side behind it
+static int schur_pack(srk_ba* h)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = dev_alloc(h, h->A->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
+    double* tail = P<double>(h->A->packed) + h->band_packed;
+    srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->A->packed), 0);
+    HIPCHK(h, hipMemcpyAsync(tail, h->A->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipGetLastError());
+    return SRK_OK;
+}
+static int schur_unpack(srk_ba* h)
+{
+    const SrkDims& d = h->d;
+    hipStream_t s = h->stream;
+    double* tail = P<double>(h->A->packed) + h->band_packed;
+    srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->A->packed), 1);
+    HIPCHK(h, hipMemcpyAsync(h->A->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipGetLastError());
+    return SRK_OK;
+}
+static int phase_schur(srk_ba* h, double c, bool local_only)
 {
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
@@ -1263,7 +1396,7 @@ static int phase_schur(srk_ba* h, double c)
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S),
                              P<double>(h->A->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
                              P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0,
-                             P<int32_t>(h->A->irr));
+                             P<int32_t>(h->A->irr), h->n_mm_uniform, h->n_mm_ragged);
     srk_launch_schur_long(s, d, c, P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S), P<double>(h->A->rhs),
                           P<int32_t>(h->lg_item), h->n_long_items, P<int32_t>(h->lg_np), P<int32_t>(h->lg_nf), P<int32_t>(h->lg_pts),
                           P<int32_t>(h->lg_frames), P<int64_t>(h->lg_obs_off), P<int32_t>(h->lg_obs));
@@ -1275,19 +1408,13 @@ static int phase_schur(srk_ba* h, double c)
     srk_launch_assemble(s, d, c, P<double>(h->Ug), P<double>(h->A->S), P<double>(h->A->rhs), h->rank == 0 ? 1.0 : 0.0,
                         P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg), P<int32_t>(h->A->irr));
     HIPCHK(h, hipGetLastError());
-    if (h->allreduce || h->comm) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
-        int rc;
-        if ((rc = dev_alloc(h, h->A->packed, (size_t)(8 * (h->band_packed + d.ld)))) != SRK_OK) return rc;
-        double* tail = P<double>(h->A->packed) + h->band_packed;
-        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->A->packed), 0);
-        HIPCHK(h, hipMemcpyAsync(tail, h->A->rhs.p, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
-        rc = exchange(h, P<double>(h->A->packed), h->band_packed + d.ld);
-        if (rc != SRK_OK) return rc;
-        srk_launch_band_pack(s, d.ld, P<int64_t>(h->band_col), P<int64_t>(h->band_off), P<double>(h->A->S), P<double>(h->A->packed), 1);
-        HIPCHK(h, hipMemcpyAsync(h->A->rhs.p, tail, (size_t)(8 * d.ld), hipMemcpyDeviceToDevice, s));
-        HIPCHK(h, hipGetLastError());
-    }
     h->last_hessian_factor = c;
+    if ((h->allreduce || h->comm) && !local_only) { // landmark shards: ONE exchange per attempt; only the band travels, the rhs rides behind it
+        int rc = schur_pack(h);
+        if (rc == SRK_OK) rc = exchange(h, P<double>(h->A->packed), h->band_packed + d.ld);
+        if (rc == SRK_OK) rc = schur_unpack(h);
+        if (rc != SRK_OK) return rc;
+    }
     return SRK_OK;
 }
 
@@ -1469,10 +1596,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     if (h->seen_global < 0) {
         double seen_d = (double)d.O;
         if (h->allreduce || h->comm) {
-            HIPCHK(h, hipMemcpyAsync(h->A->err_out.p, &seen_d, 8, hipMemcpyHostToDevice, s));
-            int rc = exchange(h, P<double>(h->A->err_out), 1);
+            HIPCHK(h, hipMemcpyAsync(h->A->err_dst, &seen_d, 8, hipMemcpyHostToDevice, s));
+            int rc = exchange(h, h->A->err_dst, 1);
             if (rc != SRK_OK) return fail_device(rc);
-            HIPCHK(h, hipMemcpyAsync(&seen_d, h->A->err_out.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(&seen_d, h->A->err_dst, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipStreamSynchronize(s));
         }
         h->seen_global = (int64_t)seen_d;
@@ -1485,7 +1612,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     int rc = phase_error(h, h->cur, nullptr);
     if (rc != SRK_OK) return fail_device(rc);
     EVREC(1);
-    HIPCHK(h, hipMemcpyAsync(&err_initial, h->A->err_out.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(&err_initial, h->A->err_dst, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     rep->ms_error += ev_ms(0, 1);
     rep->err_initial = rep->err_final = err_initial;
@@ -1551,12 +1678,15 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             if (r2 == SRK_OK) r2 = phase_error(h, h->A->trial, nullptr, true);
             if (sl == 0) EVREC(7);
             // one read-back per attempt into pinned host memory: {error, solver info, point-update info}
-            if (r2 == SRK_OK && hipMemcpyAsync(h->A->host_back, h->A->err_out.p, 24, hipMemcpyDeviceToHost, st) != hipSuccess)
+            if (r2 == SRK_OK && hipMemcpyAsync(h->A->host_back, h->A->err_dst, 24, hipMemcpyDeviceToHost, st) != hipSuccess)
                 r2 = SRK_E_DEVICE;
             if (r2 == SRK_OK && hipEventRecord(h->A->done, st) != hipSuccess) r2 = SRK_E_DEVICE;
             select_attempt(h, 0);
             return r2;
         };
+        // several ranks, damping-parallel schedule (instrumentation off): see dp_round below
+        const bool dp_mode = (h->allreduce || h->comm) && (h->world >= 2 || h->dp_force) && h->dp_schedule &&
+                             h->profile_level == 0 && h->att[1].allocated;
         // wait for slot sl's attempt and judge it exactly as the reference judges the attempt with factor `hessian_factor`
         std::function<int(int, double)> redo_unfused; // (defined below: repeats one attempt after a hand-off timeout)
         auto judge_attempt = [&](int sl) -> int {
@@ -1565,8 +1695,10 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             // (several ranks: the status words are SUMMED over the ranks, so bit 8 cannot be told from two ranks' bit 4; any
             // non-zero status of a fused solve is then taken for a possible timeout -- every rank sees the same sum and
             // repeats, a genuine failure shows again without the fused kernels)
-            const bool multi_rank = h->allreduce || h->comm;
-            if (multi_rank ? ((int)hb[1] != 0 && h->att[sl].sync.fused) : (((int)hb[1] & 8) != 0)) {
+            // (damping-parallel schedule: only the rank that solved a factor contributes its status word, bit 8 is exact, and
+            // the round loop has dealt with it before anything is judged)
+            const bool multi_rank = (h->allreduce || h->comm) && !dp_mode;
+            if (multi_rank ? ((int)hb[1] != 0 && h->att[sl].sync.fused) : (((int)hb[1] & 8) != 0 && !dp_mode)) {
                 // an in-launch hand-off of the fused solve timed out (srk_chol.hip: k_step256; its spins are bounded): the
                 // numbers of this attempt are void.  From now on the unfused launch sequence (bit-identical arithmetic);
                 // this attempt is repeated with the factor it stands for, which is `hessian_factor` at this point.
@@ -1623,6 +1755,92 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         bool spec_in_flight = false;
         int round = 0;
         const int64_t attempts_before = rep->attempts;
+        // ---- several ranks: one round = the next G damping factors c, 10c, (100c), one attempt slot each.
+        //   every rank: Schur sum of its landmarks for each factor (+ its share of the frame blocks), band packed;
+        //   band k REDUCED to rank k % world (a reduce, not an all-reduce: half the traffic, and one ncclGroup for all k);
+        //   rank k % world: unpack, factorise and solve factor k -- the G solves run at the same time on G GPUs;
+        //   corrections of factor k BROADCAST from its rank (80 KB at 1000 frames);
+        //   every rank: back-substitution, camera update and error of its shard for every factor;
+        //   ONE all-reduce of the G x {error, solver status, point-update status}; every rank judges the attempts in the
+        //   reference's order and takes the same decisions.  An iteration that needs <= G attempts costs about one solve.
+        auto dp_round = [&](int G, const double* cf) -> int {
+            double* ptrs[SRK_SLOTS];
+            int64_t counts[SRK_SLOTS];
+            int r2 = SRK_OK;
+            for (int k = 0; k < G && r2 == SRK_OK; ++k) {
+                select_attempt(h, k);
+                if (k > 0 && hipStreamWaitEvent(h->stream, h->ev_jac, 0) != hipSuccess) r2 = SRK_E_DEVICE;
+                if (r2 == SRK_OK) r2 = phase_schur(h, cf[k], true);
+                if (r2 == SRK_OK) r2 = schur_pack(h);
+                ptrs[k] = P<double>(h->A->packed);
+                counts[k] = h->band_packed + d.ld;
+            }
+            select_attempt(h, 0);
+            if (r2 == SRK_OK) r2 = coll_group(h, SRK_COLL_REDUCE, G, ptrs, counts);
+            for (int k = 0; k < G && r2 == SRK_OK; ++k) {
+                select_attempt(h, k);
+                if (h->rank == k % h->world) {
+                    r2 = schur_unpack(h);
+                    if (r2 == SRK_OK) r2 = phase_solve(h, false);
+                }
+                ptrs[k] = P<double>(h->A->dc);
+                counts[k] = d.ld;
+            }
+            select_attempt(h, 0);
+            if (r2 == SRK_OK) r2 = coll_group(h, SRK_COLL_BCAST, G, ptrs, counts);
+            for (int k = 0; k < G && r2 == SRK_OK; ++k) {
+                select_attempt(h, k);
+                r2 = phase_backsub_apply(h, cf[k]);
+                if (r2 == SRK_OK) r2 = phase_cam_apply(h);
+                if (r2 == SRK_OK) r2 = phase_error(h, h->A->trial, nullptr, true, true);
+            }
+            select_attempt(h, 0);
+            if (r2 != SRK_OK) return r2;
+            // the status words of all slots in one all-reduce, then one read-back
+            if (h->comm) {
+                for (int k = 0; k < G; ++k) {
+                    if (hipEventRecord(h->att[k].ev_b, h->att[k].stream) != hipSuccess ||
+                        hipStreamWaitEvent(h->comm_stream, h->att[k].ev_b, 0) != hipSuccess) return SRK_E_DEVICE;
+                }
+                ncclResult_t nr = rccl().AllReduce(h->status_all.p, h->status_all.p, (size_t)(8 * G), ncclDouble, ncclSum, h->comm, h->comm_stream);
+                if (nr != ncclSuccess) { h->last_error = std::string("ncclAllReduce: ") + rccl().GetErrorString(nr); return SRK_E_DEVICE; }
+                if (hipMemcpyAsync(h->dp_back, h->status_all.p, (size_t)(64 * G), hipMemcpyDeviceToHost, h->comm_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->comm_stream) != hipSuccess) return SRK_E_DEVICE;
+            } else {
+                for (int k = 0; k < G; ++k)
+                    if (hipStreamSynchronize(h->att[k].stream) != hipSuccess) return SRK_E_DEVICE;
+                if (h->allreduce(h->allreduce_ctx, P<double>(h->status_all), 8 * G) != 0) { h->last_error = "allreduce hook failed"; return SRK_E_DEVICE; }
+                if (hipMemcpy(h->dp_back, h->status_all.p, (size_t)(64 * G), hipMemcpyDeviceToHost) != hipSuccess) return SRK_E_DEVICE;
+            }
+            for (int k = 0; k < G; ++k)
+                for (int e = 0; e < 3; ++e) h->att[k].host_back[e] = h->dp_back[8 * k + e];
+            return SRK_OK;
+        };
+        while (dp_mode && !decrease) {
+            double cf[SRK_SLOTS];
+            int G = 0;
+            for (double cc = hessian_factor; G < SRK_SLOTS && h->att[G].allocated; cc *= 10) {
+                if (G > 0 && max_hessian_factor && cc > *max_hessian_factor) break; // the reference stops before such an attempt (:843-847)
+                cf[G++] = cc;
+            }
+            rc = dp_round(G, cf);
+            if (rc != SRK_OK) return fail_device(rc);
+            bool timeout = false;
+            for (int k = 0; k < G; ++k) timeout = timeout || (((int)h->att[k].host_back[1] & 8) != 0);
+            if (timeout && h->chol_fused) { // a hand-off of the fused solve timed out on the rank that solved: the round again, unfused, everywhere
+                ++h->sync_timeouts;
+                h->chol_fused = false;
+                for (auto& a : h->att) a.sync.fused = false;
+                h->poisoned = true;
+                rc = clear_poison(h);
+                if (rc != SRK_OK) return fail_device(rc);
+                continue;
+            }
+            for (int k = 0; k < G && !decrease; ++k) {
+                rc = judge_attempt(k);
+                if (rc != SRK_OK) return fail_device(rc);
+            }
+        }
         while (!decrease) {
             // speculate once this optimise call has seen a rejection (or from its second iteration on): the first
             // iteration of a fresh scene is usually accepted at once -- and after a rejected pair the third attempt
@@ -2028,7 +2246,7 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
     HIPCHK(h, hipStreamSynchronize(s));
-    HIPCHK(h, hipStreamSynchronize(h->att[1].stream));
+    for (int sl = 1; sl < SRK_SLOTS; ++sl) HIPCHK(h, hipStreamSynchronize(h->att[sl].stream));
     // reduced camera system, rhs and corrections: those of the last attempt the LM loop judged (or of the staged calls)
     struct SlotGuard {
         srk_ba* h;
@@ -2077,7 +2295,19 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
             std::vector<float> wf((size_t)(30 * d.Os));
             if ((rc = d2h(wf.data(), h->W.p, wf.size() * 4)) != SRK_OK) return rc;
             for (size_t i = 0; i < wf.size(); ++i) w[i] = (double)wf[i];
-        } else if ((rc = d2h(w.data(), h->W.p, w.size() * 8)) != SRK_OK) return rc;
+        } else {
+            // fp64 storage keeps the rank-2 factors (srk_dev.hpp SRK_WF_*): the products are formed here
+            std::vector<double> f((size_t)(SRK_WF_PLANES * d.Os));
+            if ((rc = d2h(f.data(), h->W.p, f.size() * 8)) != SRK_OK) return rc;
+            auto F = [&](int plane, int64_t o) { return plane >= 0 ? f[(size_t)(plane * d.Os + o)] : 0.0; };
+            for (int64_t o = 0; o < d.O; ++o)
+                for (int pv = 0; pv < 3; ++pv)
+                    for (int fv = 0; fv < 10; ++fv) {
+                        const int pa = fv >= 4 ? SRK_WF_AF4 + fv - 4 : (fv == 0 ? SRK_WF_AF0 : (fv == 2 ? SRK_WF_G : -1));
+                        const int pb = fv >= 4 ? SRK_WF_BF4 + fv - 4 : (fv == 1 ? SRK_WF_BF1 : (fv == 3 ? SRK_WF_G : -1));
+                        w[(size_t)((10 * pv + fv) * d.Os + o)] = F(SRK_WF_AP + pv, o) * F(pa, o) + F(SRK_WF_BP + pv, o) * F(pb, o);
+                    }
+        }
         for (int64_t i = 0; i < d.N; ++i) {
             int64_t oi = h->row_ptr_int[(size_t)i], ou = h->row_ptr_user[(size_t)h->perm[(size_t)i]];
             int64_t cnt = h->row_ptr_int[(size_t)i + 1] - oi;
@@ -2122,7 +2352,7 @@ int srk_ba_download_rcs_rows(srk_ba* h, const int64_t* rows, int64_t n_rows, dou
     if (!h || !h->have_scene || !rows || !dst || n_rows < 0) return SRK_E_STATE;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->att[1].stream));
+    for (int sl = 1; sl < SRK_SLOTS; ++sl) HIPCHK(h, hipStreamSynchronize(h->att[sl].stream));
     const SrkDims& d = h->d;
     const int64_t n = 10 * (int64_t)d.M;
     const double* S = P<double>(h->att[h->last_slot].S);

@@ -60,6 +60,54 @@ void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double
     hipLaunchKernelGGL(k_cam_pack, dim3((M + 63) / 64), dim3(64), 0, s, M, R, T, K, f0, pack);
 }
 
+// ------------------------------------------------------------------ storage of the point-frame blocks
+// Every entry of an observation's 3 x 10 block is  W[pv][fv] = Ap[pv] Af[fv] + Bp[pv] Bf[fv]  (formula 9 with the A's and
+// B's scaled by sqrt(2) / r^2): the block is a rank-2 product.  With fp64 storage (the default) the library keeps the FACTORS
+// -- 3 + 3 + 8 + 7 = 21 doubles (Af[1] = Af[3] = Bf[0] = Bf[2] = 0 and Af[2] = Bf[3]) instead of 30 products, 168 instead
+// of 240 bytes an observation for the derivative pass to write and the Schur and back-substitution passes to read -- as SoA
+// planes F[k Os + o] (SRK_WF_* in srk_dev.hpp), and every consumer forms the entries it needs with two multiply-adds.
+// The opt-in f32 storage mode keeps the 30 products as floats (120 bytes), as before.
+template <typename WT> struct WStore { static constexpr bool factored = false; };
+template <> struct WStore<double> { static constexpr bool factored = true; };
+// plane of Af[fv] / Bf[fv], or -1 where the factor is structurally zero
+__device__ __forceinline__ int srk_wf_af_plane(int fv) { return fv >= 4 ? SRK_WF_AF4 + fv - 4 : (fv == 0 ? SRK_WF_AF0 : (fv == 2 ? SRK_WF_G : -1)); }
+__device__ __forceinline__ int srk_wf_bf_plane(int fv) { return fv >= 4 ? SRK_WF_BF4 + fv - 4 : (fv == 1 ? SRK_WF_BF1 : (fv == 3 ? SRK_WF_G : -1)); }
+// entry k = 10 pv + fv of observation o, whatever the storage
+template <typename WT> __device__ __forceinline__ double w_entry(const WT* __restrict__ W, int64_t Os, int64_t o, int k)
+{
+    if constexpr (!WStore<WT>::factored) return (double)W[(int64_t)k * Os + o];
+    else {
+        const int pv = k / 10, fv = k - 10 * pv;
+        const int pa = srk_wf_af_plane(fv), pb = srk_wf_bf_plane(fv);
+        const double af = pa >= 0 ? W[(int64_t)pa * Os + o] : 0.0, bf = pb >= 0 ? W[(int64_t)pb * Os + o] : 0.0;
+        return W[(int64_t)(SRK_WF_AP + pv) * Os + o] * af + W[(int64_t)(SRK_WF_BP + pv) * Os + o] * bf;
+    }
+}
+// the block of observation o from factors scaled so that W = Ap Af + Bp Bf
+template <typename WT>
+__device__ __forceinline__ void w_store(WT* __restrict__ W, int64_t Os, int64_t o, const double (&Ap)[3], const double (&Bp)[3],
+                                        const double (&Af)[10], const double (&Bf)[10])
+{
+    WT* wp = W + o;
+    if constexpr (WStore<WT>::factored) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) { wp[(int64_t)(SRK_WF_AP + v) * Os] = Ap[v]; wp[(int64_t)(SRK_WF_BP + v) * Os] = Bp[v]; }
+        wp[(int64_t)SRK_WF_AF0 * Os] = Af[0];
+        wp[(int64_t)SRK_WF_G * Os] = Af[2];
+        wp[(int64_t)SRK_WF_BF1 * Os] = Bf[1];
+#pragma unroll
+        for (int v = 4; v < 10; ++v) { wp[(int64_t)(SRK_WF_AF4 + v - 4) * Os] = Af[v]; wp[(int64_t)(SRK_WF_BF4 + v - 4) * Os] = Bf[v]; }
+    } else {
+#pragma unroll
+        for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+            for (int fv = 0; fv < 10; ++fv) {
+                *wp = (WT)(Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]);
+                wp += Os;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ per-observation geometry
 struct ObsGeom {
     double p, q, r;
@@ -158,11 +206,21 @@ __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __r
         double Ap[3], Bp[3], Af[10], Bf[10];
         point_ab(c, g, Ap, Bp);
         frame_ab(c, g, X0, X1, X2, Af, Bf);
+        if constexpr (WStore<WT>::factored) {
+            const double sc = 0.7071067811865476 * g.s1; // sqrt(2 / r^4): both sides of every product carry it once
+            double Aps[3], Bps[3], Afs[10], Bfs[10];
 #pragma unroll
-        for (int pv = 0; pv < 3; ++pv)
+            for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * sc; Bps[v] = Bp[v] * sc; }
 #pragma unroll
-            for (int fv = 0; fv < 10; ++fv)
-                W[(int64_t)(10 * pv + fv) * d.Os + o] = (WT)((Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]) * g.s2);
+            for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * sc; Bfs[v] = Bf[v] * sc; }
+            w_store<WT>(W, d.Os, o, Aps, Bps, Afs, Bfs);
+        } else {
+#pragma unroll
+            for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+                for (int fv = 0; fv < 10; ++fv)
+                    W[(int64_t)(10 * pv + fv) * d.Os + o] = (WT)((Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]) * g.s2);
+        }
         acc[0] = (Ap[0] * Ap[0] + Bp[0] * Bp[0]) * g.s2;
         acc[1] = (Ap[0] * Ap[1] + Bp[0] * Bp[1]) * g.s2;
         acc[2] = (Ap[0] * Ap[2] + Bp[0] * Bp[2]) * g.s2;
@@ -295,14 +353,24 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
             for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * s2; Bps[v] = Bp[v] * s2; }
 #pragma unroll
             for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * s2; Bfs[v] = Bf[v] * s2; }
-            WT* wp = W + o;
+            if constexpr (WStore<WT>::factored) {
+                const double sc = sqrt(s2); // both sides of every product carry sqrt(2 / r^4) once
+                double Apq[3], Bpq[3], Afq[10], Bfq[10];
 #pragma unroll
-            for (int pv = 0; pv < 3; ++pv)
+                for (int v = 0; v < 3; ++v) { Apq[v] = Ap[v] * sc; Bpq[v] = Bp[v] * sc; }
 #pragma unroll
-                for (int fv = 0; fv < 10; ++fv) {
-                    *wp = (WT)(Aps[pv] * Af[fv] + Bps[pv] * Bf[fv]);
-                    wp += d.Os;
-                }
+                for (int v = 0; v < 10; ++v) { Afq[v] = Af[v] * sc; Bfq[v] = Bf[v] * sc; }
+                w_store<WT>(W, d.Os, o, Apq, Bpq, Afq, Bfq);
+            } else {
+                WT* wp = W + o;
+#pragma unroll
+                for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+                    for (int fv = 0; fv < 10; ++fv) {
+                        *wp = (WT)(Aps[pv] * Af[fv] + Bps[pv] * Bf[fv]);
+                        wp += d.Os;
+                    }
+            }
             acc[0] = Aps[0] * Ap[0] + Bps[0] * Bp[0];
             acc[1] = Aps[0] * Ap[1] + Bps[0] * Bp[1];
             acc[2] = Aps[0] * Ap[2] + Bps[0] * Bp[2];
@@ -501,14 +569,7 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                 const double t0 = X0 - c[30], t1 = X1 - c[31], t2 = X2 - c[32];
                 Af[7] = a1[1] * t2 - a1[2] * t1; Af[8] = a1[2] * t0 - a1[0] * t2; Af[9] = a1[0] * t1 - a1[1] * t0;
                 Bf[7] = b1[1] * t2 - b1[2] * t1; Bf[8] = b1[2] * t0 - b1[0] * t2; Bf[9] = b1[0] * t1 - b1[1] * t0;
-                WT* wp = W + o;
-#pragma unroll
-                for (int pv = 0; pv < 3; ++pv)
-#pragma unroll
-                    for (int fv = 0; fv < 10; ++fv) {
-                        *wp = (WT)(Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]);
-                        wp += d.Os;
-                    }
+                w_store<WT>(W, d.Os, o, Ap, Bp, Af, Bf); // fp64: the 21 factors; f32 storage: the 30 products
                 v9[0] = Ap[0] * Ap[0] + Bp[0] * Bp[0];
                 v9[1] = Ap[0] * Ap[1] + Bp[0] * Bp[1];
                 v9[2] = Ap[0] * Ap[2] + Bp[0] * Bp[2];
@@ -787,7 +848,7 @@ __device__ __forceinline__ void schur_one_landmark(const SrkDims& d, double c, c
         __syncthreads();
         for (int t = threadIdx.x; t < na * 30; t += 256) {
             int k = t / na, a = t - k * na;
-            sWa[a][k] = W[(int64_t)k * d.Os + o0 + a0 + a];
+            sWa[a][k] = w_entry<WT>(W, d.Os, o0 + a0 + a, k);
         }
         if (threadIdx.x < na) sFa[threadIdx.x] = obs_frame[o0 + a0 + threadIdx.x];
         __syncthreads();
@@ -807,8 +868,7 @@ __device__ __forceinline__ void schur_one_landmark(const SrkDims& d, double c, c
             for (int t = threadIdx.x; t < nb * 10; t += 256) {
                 int fv = t / nb, b = t - fv * nb;
                 int64_t ob = o0 + b0 + b;
-                double w0 = W[(int64_t)fv * d.Os + ob], w1 = W[(int64_t)(10 + fv) * d.Os + ob],
-                       w2 = W[(int64_t)(20 + fv) * d.Os + ob];
+                double w0 = w_entry<WT>(W, d.Os, ob, fv), w1 = w_entry<WT>(W, d.Os, ob, 10 + fv), w2 = w_entry<WT>(W, d.Os, ob, 20 + fv);
                 // Y = E^-1 W  (3 x 10)
                 sYb[b][fv] = Einv[0] * w0 + Einv[1] * w1 + Einv[2] * w2;
                 sYb[b][10 + fv] = Einv[3] * w0 + Einv[4] * w1 + Einv[5] * w2;
@@ -996,7 +1056,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
     // the round's PB nf consecutive observations (coalesced over q); LDS slot of (landmark q / nf, frame q % nf, k).
     // Everything per-thread is worked out here, once: the round loop below only adds the round's offset.
     const int qn = SRK_GRP_PB * nf;
-    const WT* gp[SRK_GRP_PRE];
+    int gk[SRK_GRP_PRE]; // entry (k = 10 pv + fv) of the staged element; its observation is oa + qpos
     int loff[SRK_GRP_PRE], koff[SRK_GRP_PRE], qpos[SRK_GRP_PRE];
 #pragma unroll
     for (int j = 0; j < SRK_GRP_PRE; ++j) {
@@ -1008,7 +1068,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         qpos[j] = in ? q : (1 << 30);
         koff[j] = L::WM * m + r + (r >= 5 ? L::WH - 5 : 0);
         loff[j] = in ? pl * W_LM + a * L::WS + koff[j] : 0; // uniform runs: landmark q / nf, slot q % nf
-        gp[j] = W + (in ? (int64_t)k * d.Os + q : 0);
+        gk[j] = in ? k : 0;
     }
     // Y stage map: item t = tid + i THREADS -> (staging slot pl, frame a, frame variable fv).  The same thread also
     // accumulates rhs: W^T (E^-1 g) of ITS staging slot; the PB slots of one (a, fv) are summed by the flush atomics.
@@ -1037,7 +1097,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         const int64_t oa = row_ptr[p0 + pb];
         const int nq = (int)(row_ptr[p0 + pb + nbn] - oa);
 #pragma unroll
-        for (int j = 0; j < SRK_GRP_PRE; ++j) pre[j] = qpos[j] < nq ? gp[j][oa] : 0.0;
+        for (int j = 0; j < SRK_GRP_PRE; ++j) pre[j] = qpos[j] < nq ? w_entry<WT>(W, d.Os, oa + qpos[j], gk[j]) : 0.0;
         if (ragged) {
 #pragma unroll
             for (int j = 0; j < SRK_GRP_PRE; ++j)
@@ -1241,11 +1301,10 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
             const int nbn = np - pb < PB ? np - pb : PB;
             const int64_t oa = row_ptr[p0 + pb];
             nq_pre = (int)(row_ptr[p0 + pb + nbn] - oa);
-            const WT* base = W + oa + lane;
 #pragma unroll
             for (int k = 0; k < 30; ++k) {
-                pre[k][0] = lane < nq_pre ? base[(int64_t)k * d.Os] : 0.0;
-                pre[k][1] = lane + 64 < nq_pre ? base[(int64_t)k * d.Os + 64] : 0.0;
+                pre[k][0] = lane < nq_pre ? w_entry<WT>(W, d.Os, oa + lane, k) : 0.0;
+                pre[k][1] = lane + 64 < nq_pre ? w_entry<WT>(W, d.Os, oa + lane + 64, k) : 0.0;
             }
             if (ragged) {
 #pragma unroll
@@ -1509,7 +1568,10 @@ __device__ const signed char srk_mm_tiles13[SRK_MM_CW][SRK_MM_SLOTS][2] = {
     { { 12, 8 }, { 12, 9 }, { 12, 10 }, { 12, 11 }, { 12, 12 }, { 8, 8 }, { 9, 8 }, { 9, 9 } },
     { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { -1, 0 }, { -1, 0 } },
 };
-template <typename WT>
+// RAGGED: the instantiation for runs over the UNION of different frame lists (W + Y form, masks); the other one takes the
+// uniform runs (SYRK form, double rounds).  Two kernels, two register allocations: a workgroup whose run is of the other kind
+// leaves at once, and the host launches an instantiation only when the scene has runs of its kind.
+template <typename WT, bool RAGGED>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
@@ -1551,7 +1613,8 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
     const int nfu = grp_nf[blockIdx.x];
-    const bool ragged = nfu < 0;
+    constexpr bool ragged = RAGGED;
+    if ((nfu < 0) != RAGGED) return;
     const int nf = ragged ? -nfu : nfu;
     if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
     if (tid < nf * 10) {
@@ -1578,7 +1641,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             dst[j] = -1;
             v[j] = 0;
             if (rd < 2 && q < nq) {
-                v[j] = W[(int64_t)k * d.Os + o0 + oa + q];
+                v[j] = w_entry<WT>(W, d.Os, o0 + oa + q, k);
                 int pl, a;
                 if (ragged) { pl = obs_pt[o0 + oa + q] - (int)(p0 + rd * PB); a = (int)obs_slot[o0 + oa + q]; }
                 else { pl = q / nf; a = q - pl * nf; }
@@ -1657,9 +1720,8 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
             nq_pre = sm < 3 ? rb - ra : 0;
             if (sq < nq_pre) {
-                const WT* src = W + (int64_t)(10 * sm) * d.Os + o0 + ra + sq;
 #pragma unroll
-                for (int i = 0; i < 10; ++i) pre[i] = src[(int64_t)i * d.Os];
+                for (int i = 0; i < 10; ++i) pre[i] = w_entry<WT>(W, d.Os, o0 + ra + sq, 10 * sm + i);
                 if (ragged)
                     sdst = (3 * (obs_pt[o0 + ra + sq] - (int)(p0 + r * PB)) + sm) * LDW + 10 * (int)obs_slot[o0 + ra + sq];
             }
@@ -1766,6 +1828,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int pl2 = q2 / nf, a2 = q2 - pl2 * nf;
         const int dst2 = 3 * pl2 * LDW + 10 * a2;
         double pre2[NBT][3], racc2[NBT];
+        double fap[3], fbp[3]; // fp64 storage: the observation's point-side factors; pre2[b][0 / 1] = Af / Bf of column b
 #pragma unroll
         for (int b = 0; b < NBT; ++b) racc2[b] = 0;
         int nq2 = 0;
@@ -1773,6 +1836,22 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
             nq2 = i02 < 3 ? rb - ra : 0;
             if (q2 < nq2) {
+                if constexpr (WStore<WT>::factored) {
+                    const WT* wo = W + (o0 + ra + q2);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        fap[m] = wo[(int64_t)(SRK_WF_AP + m) * d.Os];
+                        fbp[m] = wo[(int64_t)(SRK_WF_BP + m) * d.Os];
+                    }
+#pragma unroll
+                    for (int b = 0; b < NBT; ++b) {
+                        if (i02 + 3 * b < 10) { // (planes of the frame-side factors of column i02 + 3 b; -1: structurally zero)
+                            const int pa = srk_wf_af_plane(i02 + 3 * b), pb = srk_wf_bf_plane(i02 + 3 * b);
+                            pre2[b][0] = pa >= 0 ? wo[(int64_t)pa * d.Os] : 0.0;
+                            pre2[b][1] = pb >= 0 ? wo[(int64_t)pb * d.Os] : 0.0;
+                        }
+                    }
+                } else {
                 // plane base (wave-uniform: scalar registers) + one 32-bit lane offset: no 64-bit address arithmetic per load
                 const unsigned voff = (unsigned)(o0 + ra + q2) + (unsigned)i02 * (unsigned)d.Os;
 #pragma unroll
@@ -1785,6 +1864,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                         }
                     }
                 }
+                }
             }
         };
         // (round 3: the SYRK form -- the lane forms z = L^-1 w for its columns, a 3 x 3 forward substitution on the registers
@@ -1796,6 +1876,23 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 const double2* E2 = reinterpret_cast<const double2*>(sE[pb + pl2]);
                 const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
                 const double i0 = e01.x, l10 = e01.y, i1 = e23.x, l20 = e23.y, l21 = e45.x, i2 = e45.y;
+                if constexpr (WStore<WT>::factored) {
+                    // Z = L^-1 (Ap Af + Bp Bf) = (L^-1 Ap) Af + (L^-1 Bp) Bf: the substitution once per observation, then two
+                    // multiply-adds an entry
+                    const double a0 = fap[0] * i0, a1 = (fap[1] - l10 * a0) * i1, a2 = (fap[2] - l20 * a0 - l21 * a1) * i2;
+                    const double b0 = fbp[0] * i0, b1 = (fbp[1] - l10 * b0) * i1, b2 = (fbp[2] - l20 * b0 - l21 * b1) * i2;
+                    const double ah = a0 * e67.x + a1 * e67.y + a2 * e89.x, bh = b0 * e67.x + b1 * e67.y + b2 * e89.x;
+#pragma unroll
+                    for (int b = 0; b < NBT; ++b) {
+                        const int i = i02 + 3 * b;
+                        if (i < 10) {
+                            const double af = pre2[b][0], bf = pre2[b][1];
+                            double* wp = bw + dst2 + i;
+                            wp[0] = a0 * af + b0 * bf; wp[LDW] = a1 * af + b1 * bf; wp[2 * LDW] = a2 * af + b2 * bf;
+                            racc2[b] += ah * af + bh * bf;
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int b = 0; b < NBT; ++b) {
                     const int i = i02 + 3 * b;
@@ -1807,6 +1904,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                         wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
                         racc2[b] += z0 * e67.x + z1 * e67.y + z2 * e89.x;
                     }
+                }
                 }
             }
             // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
@@ -2126,11 +2224,10 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
 #pragma unroll
         for (int i = 0; i < 15; ++i) pre[i] = 0.0;
         if (o >= 0) {
-            const WT* src = W + (int64_t)(5 * sh) * d.Os + o;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) pre[5 * m + i] = (double)src[(int64_t)(10 * m + i) * d.Os];
+                for (int i = 0; i < 5; ++i) pre[5 * m + i] = w_entry<WT>(W, d.Os, o, 10 * m + 5 * sh + i);
         }
     };
     double racc[5] = { 0, 0, 0, 0, 0 };
@@ -2220,7 +2317,7 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
                               const int32_t* grp_frames, int64_t n_groups, int64_t n_wide, int64_t n_mid,
-                              int fp32_accumulate, int32_t* irr)
+                              int fp32_accumulate, int32_t* irr, int64_t n_mm_uniform, int64_t n_mm_ragged)
 {
     if (n_groups <= 0) return;
     // runs over at most SRK_WS_NF frames go to the MFMA kernel, fp64 only (the opt-in fp32 accumulation keeps the packed
@@ -2245,8 +2342,16 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
     } while (0)
     if (!no_ws && n_wide + n_mid < n_groups) { // runs over at most SRK_WS_NF frames: the MFMA kernel
         if (env_valu) SRK_SCHUR_LAUNCH(k_schur_ws, block, double, );
-        else if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);
-        else hipLaunchKernelGGL((k_schur_mm<double>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);
+        else {
+            if (n_mm_uniform > 0) {
+                if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, false>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);
+                else hipLaunchKernelGGL((k_schur_mm<double, false>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);
+            }
+            if (n_mm_ragged > 0) {
+                if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, true>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);
+                else hipLaunchKernelGGL((k_schur_mm<double, true>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);
+            }
+        }
     }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread
         if (fp32_accumulate) SRK_SCHUR_LAUNCH_SKIP(k_schur_grouped, 1, float, );
@@ -2355,10 +2460,26 @@ __global__ __launch_bounds__(256) void k_backsub_obs(SrkDims d, const int32_t* _
         double xv[10];
 #pragma unroll
         for (int fv = 0; fv < 10; ++fv) xv[fv] = x[fv];
+        if constexpr (WStore<WT>::factored) {
+            // W x = Ap (Af . x) + Bp (Bf . x): 21 loads and 22 multiply-adds instead of 30 and 30
+            const WT* wp = W + o;
+            const double gq = wp[(int64_t)SRK_WF_G * d.Os];
+            double sa = wp[(int64_t)SRK_WF_AF0 * d.Os] * xv[0] + gq * xv[2];
+            double sb = wp[(int64_t)SRK_WF_BF1 * d.Os] * xv[1] + gq * xv[3];
 #pragma unroll
-        for (int pv = 0; pv < 3; ++pv)
+            for (int fv = 4; fv < 10; ++fv) {
+                sa += wp[(int64_t)(SRK_WF_AF4 + fv - 4) * d.Os] * xv[fv];
+                sb += wp[(int64_t)(SRK_WF_BF4 + fv - 4) * d.Os] * xv[fv];
+            }
 #pragma unroll
-            for (int fv = 0; fv < 10; ++fv) t[pv] += W[(int64_t)(10 * pv + fv) * d.Os + o] * xv[fv];
+            for (int pv = 0; pv < 3; ++pv)
+                t[pv] = wp[(int64_t)(SRK_WF_AP + pv) * d.Os] * sa + wp[(int64_t)(SRK_WF_BP + pv) * d.Os] * sb;
+        } else {
+#pragma unroll
+            for (int pv = 0; pv < 3; ++pv)
+#pragma unroll
+                for (int fv = 0; fv < 10; ++fv) t[pv] += W[(int64_t)(10 * pv + fv) * d.Os + o] * xv[fv];
+        }
     }
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) {

@@ -7,8 +7,9 @@
 //              42 1/fx  43 u0/(f0 fx)  44 1/fy  45 v0/(f0 fy)  46 1/f0  47 f0
 //   obs      point-major CSR: row_ptr[N+1] i64, obs_frame[O] i32, obs_pt[O] i32, obs_uv[O][2]
 //            frame-major copy:  col_ptr[M+1] i64, fobs_pt[O] i32, fobs_uv[O][2]
-//   W        [30][Os]  point-frame blocks, structure-of-arrays: element k = 10*pv + fv of observation o
-//            lives at W[k*Os + o] (Os = O rounded up to 64) -> every store/load is lane-contiguous
+//   W        fp64 storage (default): [21][Os] the rank-2 FACTORS of the point-frame blocks (SRK_WF_* below), structure-of-
+//            arrays, plane k of observation o at W[k*Os + o] (Os = O rounded up to 64): every store/load is lane-contiguous;
+//            f32 storage mode: [30][Os] floats, element k = 10*pv + fv of observation o at W[k*Os + o]
 //   Vg       [9][Ns]   per point: V00 V01 V02 V11 V12 V22 g0 g1 g2 (SoA, Ns = N rounded up to 64)
 //   Ug       [M][65]   per frame: 55 upper-triangle entries of the 10x10 block (row-major order) + 10 gradient
 //   S        [ld][ld]  padded reduced camera system, row-major, LOWER triangle authoritative;
@@ -22,6 +23,16 @@
 
 #define SRK_CAM_PACK 48
 #define SRK_UG 65
+// fp64 storage of the point-frame blocks: the rank-2 factors of W[pv][fv] = Ap[pv] Af[fv] + Bp[pv] Bf[fv] as SoA planes
+// (srk_ba_kernels.hip: "storage of the point-frame blocks"); Af[1] = Af[3] = Bf[0] = Bf[2] = 0, Af[2] = Bf[3] = G
+#define SRK_WF_AP 0   // planes 0..2   Ap[0..2]
+#define SRK_WF_BP 3   // planes 3..5   Bp[0..2]
+#define SRK_WF_AF0 6  // Af[0]
+#define SRK_WF_G 7    // Af[2] = Bf[3]
+#define SRK_WF_AF4 8  // planes 8..13  Af[4..9]
+#define SRK_WF_BF1 14 // Bf[1]
+#define SRK_WF_BF4 15 // planes 15..20 Bf[4..9]
+#define SRK_WF_PLANES 21
 
 struct SrkDims {
     int64_t N, O, Os, Ns;
@@ -74,7 +85,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               int64_t n_wide /* runs with more than SRK_GRP_NF1_HOST frames */,
                               int64_t n_mid /* runs with SRK_WS_NF_HOST < frames <= SRK_GRP_NF1_HOST */,
                               int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */,
-                              int32_t* irr /* [0] count + list of landmarks k_schur_mm hands back to the inverse path */);
+                              int32_t* irr /* [0] count + list of landmarks k_schur_mm hands back to the inverse path */,
+                              int64_t n_mm_uniform, int64_t n_mm_ragged /* runs of <= SRK_WS_NF_HOST frames by kind */);
 // tracks longer than SRK_GRP_MAXNF_HOST frames: runs of <= SRK_LONG_PTS_HOST landmarks over a frame set of
 // <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur
 #define SRK_LONG_PTS_HOST 128

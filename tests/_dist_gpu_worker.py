@@ -10,7 +10,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run(rank, world, port, out_dir, spec_kwargs, iters):
+def run(rank, world, port, out_dir, spec_kwargs, iters, schedule="dp"):
+    os.environ["SRK_MULTI_SCHEDULE"] = schedule  # read by srk_ba_create: "dp" (default) or "allreduce"
     os.environ["SRK_DEBUG"] = "1"  # per-attempt trace on stderr: shows up in the pytest log when an assertion fails
     import torch.distributed as dist
     import surikatoko_amd as sa

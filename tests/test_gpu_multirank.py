@@ -31,14 +31,19 @@ def _free_port():
 C3 = dict(n_frames=1000, grid_nx=400, grid_ny=250, vis_window=20)
 
 
+# schedule "dp" (default at world >= 2): damping-parallel -- every rank builds the round's two or three damping factors on its
+# shard, band k is reduced to rank k, rank k solves and broadcasts its corrections, all ranks score every factor;
+# "allreduce": the round-2 schedule (band all-reduced, every rank solves redundantly, speculative pairs)
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,spec_kwargs,min_chunks", [
-    (2, dict(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7), 0),                       # single skyline chain
-    (3, dict(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2), 2),   # nested plan
-    (2, C3, 8),
-    (4, C3, 8),
-], ids=["w2_30cam", "w3_400cam", "w2_C3_1kcam_100kpt", "w4_C3_1kcam_100kpt"])
-def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs, min_chunks):
+@pytest.mark.parametrize("world,spec_kwargs,min_chunks,schedule", [
+    (2, dict(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7), 0, "dp"),                       # single skyline chain
+    (2, dict(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7), 0, "allreduce"),
+    (3, dict(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2), 2, "dp"),   # nested plan, three factors a round
+    (3, dict(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2), 2, "allreduce"),
+    (2, C3, 8, "dp"),
+    (4, C3, 8, "dp"),
+], ids=["w2_30cam", "w2_30cam_allreduce", "w3_400cam", "w3_400cam_allreduce", "w2_C3_1kcam_100kpt", "w4_C3_1kcam_100kpt"])
+def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs, min_chunks, schedule):
     import torch.multiprocessing as mp
     import _dist_gpu_worker
     iters = 3  # far from convergence: no accept / reject decision is a near tie that summation order could flip
@@ -52,7 +57,8 @@ def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs, min_ch
     ref_rep = (rep.iterations, rep.attempts, rep.err_initial, rep.err_final, rep.seen, rep.status)
     ba.close()
 
-    mp.spawn(_dist_gpu_worker.run, args=(world, _free_port(), str(tmp_path), spec_kwargs, iters), nprocs=world, join=True)
+    mp.spawn(_dist_gpu_worker.run, args=(world, _free_port(), str(tmp_path), spec_kwargs, iters, schedule), nprocs=world,
+             join=True)
     res = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     assert res[0]["lo"] == 0 and res[-1]["hi"] == ref.N
     for r in range(world):
@@ -62,7 +68,8 @@ def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs, min_ch
         assert got == (ref_rep[0], ref_rep[1], ref_rep[4], ref_rep[5]), (r, got, ref_rep, float(z["err_final"]))
         assert float(z["err_initial"]) == pytest.approx(ref_rep[2], rel=1e-12)
         assert float(z["err_final"]) == pytest.approx(ref_rep[3], rel=1e-8)
-        # every rank solved the same all-reduced system with the same deterministic solver
+        # every rank applied the same corrections (dp: broadcast from the rank that solved; allreduce: every rank solved
+        # the same all-reduced system with the same deterministic solver)
         assert np.array_equal(z["cam_R"], res[0]["cam_R"]) and np.array_equal(z["cam_T"], res[0]["cam_T"]), \
             (r, float(np.abs(z["cam_T"] - res[0]["cam_T"]).max()))
         dT, dR = float(np.abs(z["cam_T"] - ref.cam_T).max()), float(np.abs(z["cam_R"] - ref.cam_R).max())

@@ -890,6 +890,45 @@ def test_native_rccl_two_communicators_keep_the_attempt_pairs_world_size_1(orc):
         ba.close()
 
 
+@pytest.mark.parametrize("native", [True, False])
+def test_damping_parallel_schedule_world_size_1(orc, native, monkeypatch):
+    """The multi-rank schedule of DESIGN 6 (three damping factors a round, band k reduced to rank k, corrections broadcast,
+    one all-reduce of all status words) forced at world size 1 (SRK_MULTI_SCHEDULE=dp_force) -- all one GPU can run of it:
+    natively every ncclReduce / ncclBroadcast / ncclAllReduce goes through the handle's communicator on its collective
+    stream inside ncclGroups with the event hand-offs to the three slot streams; with the callback the same program order
+    runs through host-blocking sums.  Same accept / reject sequence and numbers as the oracle's sequential loop."""
+    monkeypatch.setenv("SRK_MULTI_SCHEDULE", "dp_force")
+    spec = SCENES["ragged_wave"]
+    sc = sa.generate_scene(spec)
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        calls = []
+        if native:
+            ba.rccl_init(ba.rccl_unique_id(), 0, 1)
+        else:
+            from surikatoko_amd._lib import ALLREDUCE_FN
+            hook = ALLREDUCE_FN(lambda ctx, ptr, n: calls.append(n) or 0)
+            ba.set_allreduce(hook, 0, 1)
+        so = _orc_scene(orc, sc)
+        rc_o, rep_o = orc.compute_inplace(spec.f0, so, 1e-7, 1e6, 40)
+        crit = sa.BundleAdjustmentKanataniTermCriteria()
+        crit.AllowedReprojErrRelativeChange(1e-7)
+        crit.MaxHessianFactor(1e6)
+        sg = sc.copy()
+        ok = ba.ComputeInplace(spec.f0, sg, crit, 40)
+        rep = ba.report
+        assert ok == (rc_o == 0) and sa.status_string(rep.status) == orc.status_string(rep_o.status)
+        assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
+        assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+        assert np.abs(sg.points - so.points).max() < 1e-6
+        assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
+        assert ba.solver_sync_timeouts() == 0
+        if not native:
+            assert 24 in calls, "the three slots' status words travel in one sum"
+    finally:
+        ba.close()
+
+
 def test_native_rccl_handles_release_both_communicators():
     """srk_ba_destroy / srk_ba_set_allreduce release the second slot's communicator as well as the first (it used to leak
     with every handle that had used the two-communicator path): create / init both / close in a loop at world size 1, and

@@ -248,3 +248,27 @@ def test_demo_multi_view_factorization_cli(orc, tmp_path):
         assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
         assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6 * scale
     assert (out["ba_iterations"], out["ba_attempts"]) == (its, atts)
+
+
+@pytest.mark.gpu
+def test_demo_multi_view_factorization_full_flagfile_ends_at_frame_29():
+    """The reference flagfile's whole camera path (60 frames, cpp_impl/flagfile-demo-multi-view-factorization.txt) through
+    the drop-in: where tracking ends and why.  Frames 0-1 come from the ground truth, frames 2..28 are integrated (nine BA
+    calls on the way); frame 29 -- the first one after the viewer's path turns its first corner -- shares only 4
+    reconstructed tracks with its best anchor (frame 27).  Four points give 8 of the 11 equations the 12-unknown motion
+    system needs (multi-view-factorization.cpp:107-189): srk_mvf_relative_motion refuses (< 6 points) and the drop-in stops
+    integrating, logging the reason.  The reference driver only gives up when there are NO common points (:262-270); with
+    4 it would take whatever null vector its SVD returns and carry on with a meaningless pose ("diverged cam localiz",
+    :283-295).  No fixture of the reference pins either behaviour."""
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "demos", "demo-multi-view-factorization")
+    if not os.path.exists(exe):
+        pytest.skip("demos not built")
+    out, log = _run([exe, "--flagfile=" + os.path.join(ROOT, "demos", "flagfile-demo-multi-view-factorization.txt"),
+                     "--ba_max_iterations=50"], ROOT)
+    assert out["world_points"] == 81 * 41
+    assert (out["frames"], out["integrated_frames"], out["failed_frames"]) == (29, 27, 31)
+    assert "f=29 anchored on f=27 using common_points=4" in log
+    assert "tracking lost at frame 29: relative motion from 4 common points failed" in log
+    assert out["ba_calls"] >= 5 and out["max_pose_diff"] < 1e-3 and out["last_reproj_err"] < 1e-3
+    assert out["ba_last_frames"] == 29
