@@ -319,7 +319,6 @@ void srk_ba_destroy(srk_ba* h)
     for (auto& a : h->att) {
         for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
-        srk_chol_sync_free(&a.sync);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
         if (a.ev_a) hipEventDestroy(a.ev_a);
@@ -1041,7 +1040,8 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     // several ranks, damping-parallel schedule: one slot per damping factor of a round (at most three)
     const bool multi_upload = h->allreduce || h->comm;
     const int n_slots = (multi_upload && h->dp_schedule && (h->world >= 2 || h->dp_force))
-                            ? (h->dp_force ? SRK_SLOTS : std::min(SRK_SLOTS, h->world)) : (h->speculate ? 2 : 1);
+                            ? (h->dp_force ? SRK_SLOTS : std::min(SRK_SLOTS, h->world))
+                            : (h->speculate ? (multi_upload ? 2 : SRK_SLOTS) : 1);
     for (int w = 0; w < SRK_SLOTS + 1; ++w) {
         if (w > n_slots) continue;
         ALLOC(h->pts[w], 24 * N);
@@ -1659,7 +1659,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             select_attempt(h, sl);
             hipStream_t st = h->stream;
             int r2 = SRK_OK;
-            if (sl == 1 && hipStreamWaitEvent(st, h->ev_jac, 0) != hipSuccess) r2 = SRK_E_DEVICE;
+            if (sl >= 1 && hipStreamWaitEvent(st, h->ev_jac, 0) != hipSuccess) r2 = SRK_E_DEVICE;
             if (sl == 0) EVREC(2);
             if (r2 == SRK_OK) r2 = phase_schur(h, c);
             if (sl == 0) EVREC(3);
@@ -1752,7 +1752,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         const bool multi = h->allreduce || h->comm;
         const bool can_speculate = h->speculate && h->att[1].allocated && h->profile_level == 0 &&
                                    (!multi || (h->spec_multi && (h->allreduce || h->comm2)));
-        bool spec_in_flight = false;
+        unsigned spec_in_flight = 0; // slots whose speculative attempt has been enqueued and not judged
         int round = 0;
         const int64_t attempts_before = rep->attempts;
         // ---- several ranks: one round = the next G damping factors c, 10c, (100c), one attempt slot each.
@@ -1847,23 +1847,31 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             // usually is the last one: it runs alone unless the previous iteration needed four or more (then the damping
             // factor has a long way to climb and pairs pay again)
             const bool pair_pays = round == 0 ? (spec_wanted || rep->iterations >= 1) : (round >= 2 || prev_attempts >= 4);
-            const bool speculate_now = can_speculate && pair_pays &&
-                                       !(max_hessian_factor && hessian_factor * 10 > *max_hessian_factor);
+            // (round 3) a TRIPLE when the previous iteration needed three attempts or more: late in a run on the circle-grid
+            // scenes almost every iteration rejects c / 10 and c and accepts 10 c -- a pair plus a lone third attempt then
+            // paid two solve chains in sequence (3.3 ms); three Schur sums back to back and three solves side by side do not
+            int want = 1;
+            if (can_speculate && pair_pays) want = (round == 0 && prev_attempts >= 3 && h->att[2].allocated && !multi) ? 3 : 2;
+            int n_now = 1; // attempts enqueued this round: the factors hessian_factor * 10^k that the cap allows
+            for (double cc = hessian_factor * 10; n_now < want && !(max_hessian_factor && cc > *max_hessian_factor); cc *= 10) ++n_now;
+            const bool speculate_now = n_now >= 2;
             ++round;
-            // one rank: both Schur sums first (the second would otherwise wait behind ~0.6 ms of launch calls), then both
+            // one rank: all Schur sums first (a later one would otherwise wait behind ~0.6 ms of launch calls), then the
             // solves.  Several ranks: a Schur phase ends in a blocking exchange, so slot 0's solve is enqueued before it
             // and runs under slot 1's Schur sum and exchange.
-            rc = enqueue_schur(0, hessian_factor);
+            double cfk[SRK_SLOTS];
+            for (int k = 0; k < SRK_SLOTS; ++k) cfk[k] = k == 0 ? hessian_factor : cfk[k - 1] * 10;
+            rc = enqueue_schur(0, cfk[0]);
             if (h->allreduce || h->comm) {
-                if (rc == SRK_OK) rc = enqueue_rest(0, hessian_factor);
-                if (rc == SRK_OK && speculate_now) rc = enqueue_schur(1, hessian_factor * 10);
+                if (rc == SRK_OK) rc = enqueue_rest(0, cfk[0]);
+                if (rc == SRK_OK && speculate_now) rc = enqueue_schur(1, cfk[1]);
             } else {
-                if (rc == SRK_OK && speculate_now) rc = enqueue_schur(1, hessian_factor * 10);
-                if (rc == SRK_OK) rc = enqueue_rest(0, hessian_factor);
+                for (int k = 1; k < n_now && rc == SRK_OK; ++k) rc = enqueue_schur(k, cfk[k]);
+                if (rc == SRK_OK) rc = enqueue_rest(0, cfk[0]);
             }
-            if (rc == SRK_OK && speculate_now) rc = enqueue_rest(1, hessian_factor * 10);
+            for (int k = 1; k < n_now && rc == SRK_OK; ++k) rc = enqueue_rest(k, cfk[k]);
             if (rc != SRK_OK) return fail_device(rc);
-            if (speculate_now) spec_in_flight = true;
+            for (int k = 1; k < n_now; ++k) spec_in_flight |= 1u << k;
             rc = judge_attempt(0);
             if (rc != SRK_OK) return fail_device(rc);
             if (!jac_timed) {
@@ -1885,18 +1893,19 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
                 rep->solve_mfma_flops += h->att[0].solve_prof.flops;
             }
             if (!decrease) spec_wanted = true; // a rejection: from now on pairs pay
-            if (!decrease && speculate_now) { // the successor was computed meanwhile, with exactly this factor
-                rc = judge_attempt(1);
+            for (int k = 1; k < n_now && !decrease; ++k) { // the successors were computed meanwhile, with exactly these factors
+                rc = judge_attempt(k);
                 if (rc != SRK_OK) return fail_device(rc);
-                spec_in_flight = false;
+                spec_in_flight &= ~(1u << k);
             }
         }
         prev_attempts = rep->attempts - attempts_before;
         if (spec_in_flight) {
-            // a speculative attempt nobody needs is still running: later work on the main stream (the next derivatives
-            // overwrite what it reads) must come after it; nothing on the host waits
-            HIPCHK(h, hipStreamWaitEvent(s, h->att[1].done, 0));
-            spec_in_flight = false;
+            // speculative attempts nobody needs are still running: later work on the main stream (the next derivatives
+            // overwrite what they read) must come after them; nothing on the host waits
+            for (int k = 1; k < SRK_SLOTS; ++k)
+                if (spec_in_flight & (1u << k)) HIPCHK(h, hipStreamWaitEvent(s, h->att[k].done, 0));
+            spec_in_flight = 0;
             spec_drain = true;
         }
         if (decrease != 1) { // :857-873
@@ -1921,8 +1930,11 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
         hessian_factor /= 10; // :889
     }
     if (spec_drain) {
-        HIPCHK(h, hipStreamSynchronize(h->att[1].stream)); // leave no speculative work behind
-        if (h->att[1].host_back[1] != 0.0 || h->att[1].host_back[2] != 0.0) h->poisoned = true; // a dropped attempt that failed
+        for (int k = 1; k < SRK_SLOTS; ++k) {
+            if (!h->att[k].allocated) continue;
+            HIPCHK(h, hipStreamSynchronize(h->att[k].stream)); // leave no speculative work behind
+            if (h->att[k].host_back[1] != 0.0 || h->att[k].host_back[2] != 0.0) h->poisoned = true; // a dropped attempt that failed
+        }
     }
     select_attempt(h, 0);
     rep->hessian_factor = hessian_factor;

@@ -27,9 +27,6 @@
 // batch of one.  The solver has no atomics and a fixed summation order (bit-reproducible).
 #include "srk_dev.hpp"
 
-#include <algorithm>
-#include <cstring>
-
 #define NB 64
 #define NBO SRK_CHOL_NB      // 256, outer panel
 #define TL 128               // trailing-update tile
@@ -746,21 +743,8 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
         SST(1 + 6 * d);
         st_wait(fl, (1u << ST_F(d)) | (d > 0 ? 1u << ST_Y(d - 1) : 0u), epoch, info);
         SST(2 + 6 * d);
-        {
-            // L_dd: the tile's loads go out first, the pending w update (a global load of y and a dot product) runs under
-            // their latency, then the tile lands in LDS
-            const int ti = tid >> 2, tcb = (tid & 3) * 16;
-            const double2* src = reinterpret_cast<const double2*>(A + (k0 + d * NB + ti) * ld + k0 + d * NB + tcb);
-            double2 tv[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) tv[t] = src[t];
-            if (d > 0) w_update(d - 1);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                sD[ti][tcb + 2 * t] = tv[t].x;
-                sD[ti][tcb + 2 * t + 1] = tv[t].y;
-            }
-        }
+        if (d > 0) w_update(d - 1);
+        st_load_tile<false>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
         __syncthreads();
         if (tid < NB) sInv[tid] = fast_rcp(sD[tid][tid]);
         __syncthreads();
@@ -795,23 +779,17 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
         unsigned need = 0;
         for (int t = d + 1; t <= tmax; ++t)
             if (t != mytile) need |= 1u << ST_G(t, d);
-        // The diagonal workgroup whose own tile comes next (mytile == d + 1) is the critical one of this sub-step -- sweep,
-        // update its diagonal tile, factor it -- and nobody needs its X before that tile is factored: its X stores go out
-        // here, the flag only after the update (the stores' drain, ~1.2 us, runs under the MFMAs instead of in front of them)
-        const bool defer_flag = mytile < 4 && mytile == d + 1;
         if (mytile < 4) {
             __syncthreads();
             publish_tile(sA, A + r0 * ld + k0 + d * NB);
-            if (!defer_flag) st_publish(fl + ST_G(mytile, d), epoch);
+            st_publish(fl + ST_G(mytile, d), epoch);
         } else {
 #pragma unroll
             for (int m = 0; m < 16; ++m) rowp[d * NB + 4 * m + q] = a[m];
         }
         SST(5 + 6 * d);
         if (need) st_wait(fl, need, epoch, info);
-        else if (!defer_flag || mytile >= 4) __syncthreads(); // sA is written; every wave is done with L_dd in sD
-        // (defer_flag: the barrier before publish_tile already ordered sA; L_dd in sD is not overwritten before the update's
-        // own barrier below -- the diagonal tile's update reads sA only and writes sD behind a barrier)
+        else __syncthreads(); // sA is written; every wave is done with L_dd in sD
         SST(6 + 6 * d);
         // rank-64 update of this workgroup's tiles (., t), t = d + 1 .. tmax:  C -= X X_td^T.  The B operand X_td of the next
         // tile is fetched into registers while this one is multiplied.
@@ -881,8 +859,7 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
                         for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
             }
         }
-        if (defer_flag) st_publish(fl + ST_G(mytile, d), epoch); // (drains, barrier, flag)
-        else __syncthreads(); // the updates' stores are complete before the next sub-step loads its columns; sD is free
+        __syncthreads(); // the updates' stores are complete before the next sub-step loads its columns; sD is free
     }
     // (row workgroups only; a diagonal workgroup's w_t became y_t)
     st_wait(fl, 1u << ST_Y(NBO / NB - 1), epoch, info);
@@ -1092,31 +1069,23 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
 // j in [col_begin, 256 K).  Every product is "one column per lane, the rows split over the four waves, partial sums
 // combined through LDS": short independent load chains instead of 64- and 256-long ones.
 #define BWD_COLS 64
-// The bodies below serve two kernels each: the stand-alone launches (k_bwd256, k_bwd_border: plain stores, a kernel boundary
-// between dependent steps) and k_bwd_all, the whole backward substitution of a nested solve as ONE launch whose steps are
-// separated by grid barriers (WT = true: what a later step of another workgroup reads leaves as write-through stores).
-// Same arithmetic in the same order either way.
-template <bool WT> __device__ __forceinline__ void bwd_store(double* p, double v)
-{
-    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_store_dwordx2 sc1
-    else *p = v;
-}
 // finite: the reference's allFinite check of the solution (:1912-1913) where this level's x IS the final solution (NULL below)
-template <bool WT>
-__device__ __forceinline__ void bwd256_body(const CholItem& it, int64_t K, int64_t col_begin, int bx, int* __restrict__ finite,
-                                            double* sv /*[NBO]*/, double (*sp)[NBO - NB] /*[4]*/)
+__global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholStep Kst, const CholStep cbeg, int* __restrict__ finite)
 {
+    __shared__ double sv[NBO];
+    __shared__ double sp[4][NBO - NB];
+    const int64_t K = Kst.v[blockIdx.z], col_begin = cbeg.v[blockIdx.z];
     if (K < 0) return;
     const int64_t k0 = K * NBO;
     {
         const int64_t cols = k0 - col_begin;
-        if ((int64_t)bx >= (cols > 0 ? (cols + BWD_COLS - 1) / BWD_COLS : 1)) return;
+        if ((int64_t)blockIdx.x >= (cols > 0 ? (cols + BWD_COLS - 1) / BWD_COLS : 1)) return;
     }
-    const double* __restrict__ A = it.A;
-    const double* __restrict__ Dinv = it.dinv;
-    double* __restrict__ y = it.y;
-    double* __restrict__ x = it.x;
-    const int64_t ld = it.ld;
+    const double* __restrict__ A = B.it[blockIdx.z].A;
+    const double* __restrict__ Dinv = B.it[blockIdx.z].dinv;
+    double* __restrict__ y = B.it[blockIdx.z].y;
+    double* __restrict__ x = B.it[blockIdx.z].x;
+    const int64_t ld = B.it[blockIdx.z].ld;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     sv[t] = y[k0 + t];
     __syncthreads();
@@ -1155,11 +1124,11 @@ __device__ __forceinline__ void bwd256_body(const CholItem& it, int64_t K, int64
         if (t < sub * NB) sv[t] -= (sp[0][t] + sp[1][t]) + (sp[2][t] + sp[3][t]);
         __syncthreads();
     }
-    if (bx == 0) {
-        bwd_store<WT>(x + k0 + t, sv[t]);
+    if (blockIdx.x == 0) {
+        x[k0 + t] = sv[t];
         if (finite && !isfinite(sv[t])) atomicOr(finite, 4);
     }
-    const int64_t j = col_begin + (int64_t)bx * BWD_COLS + lane;
+    const int64_t j = col_begin + (int64_t)blockIdx.x * BWD_COLS + lane;
     double acc = 0;
     if (j < k0) {
         const double* Lc = A + (k0 + 64 * wv) * ld + j;
@@ -1168,13 +1137,7 @@ __device__ __forceinline__ void bwd256_body(const CholItem& it, int64_t K, int64
     }
     sp[wv][lane] = acc;
     __syncthreads();
-    if (wv == 0 && j < k0) bwd_store<WT>(y + j, y[j] - ((sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane])));
-}
-__global__ __launch_bounds__(256) void k_bwd256(const CholBatch B, const CholStep Kst, const CholStep cbeg, int* __restrict__ finite)
-{
-    __shared__ double sv[NBO];
-    __shared__ double sp[4][NBO - NB];
-    bwd256_body<false>(B.it[blockIdx.z], Kst.v[blockIdx.z], cbeg.v[blockIdx.z], (int)blockIdx.x, finite, sv, sp);
+    if (wv == 0 && j < k0) y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -1272,12 +1235,7 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
 
 // chol_bwd: x = L^-T y over the first `ncols` columns of every item (the border part, if any, has been folded into y
 // already).  Launch t serves outer panel nout_i - 1 - t of item i.
-struct BwdPhase;
-struct BwdRecorder { std::vector<BwdPhase>* phases; }; // non-null: the steps are recorded for k_bwd_all instead of launched
-static void record_bwd256(BwdRecorder* rec, const CholBatch& B, int n, const CholStep& Kst, const CholStep& cbeg, int64_t blocks,
-                          bool check_finite);
-static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, SrkSolveProf* prof, int* d_finite,
-                     BwdRecorder* rec = nullptr)
+static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostItem* H, SrkSolveProf* prof, int* d_finite)
 {
     int64_t nout = 0;
     for (int i = 0; i < n; ++i) nout = std::max(nout, B.it[i].ncols / NBO);
@@ -1298,8 +1256,7 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
             Kst.v[i] = K;
             cbeg.v[i] = cb;
         }
-        if (rec) record_bwd256(rec, B, n, Kst, cbeg, blocks, d_finite != nullptr);
-        else LAUNCH(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg, d_finite);
+        LAUNCH(k_bwd256, dim3((unsigned)blocks, 1, (unsigned)n), dim3(256), 0, s, B, Kst, cbeg, d_finite);
     }
 }
 
@@ -1441,18 +1398,20 @@ __global__ __launch_bounds__(256) void k_sep_reduce(const CholBatch B, int64_t s
 // The first column workgroup of chunk c also places the solution of the separator below it into the level's solution
 // vector x (and checks it where x is the final solution): with the chunk interiors written there directly by k_bwd256
 // (their CholItem::x points into x), no scatter launch is left.
-template <bool WT>
-__device__ __forceinline__ void bwd_border_body(const CholItem& it, int c, int bx, int P, int64_t sepw, const double* __restrict__ xs,
-                                                const int64_t* __restrict__ sep_start, double* __restrict__ x,
-                                                int* __restrict__ finite, double* sx /*[2 SRK_MAX_SEPW]*/, double (*sp)[64] /*[4]*/)
+__global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs,
+                                                    const int64_t* __restrict__ sep_start, double* __restrict__ x,
+                                                    int* __restrict__ finite)
 {
-    const int64_t nc = it.ncols, ldc = it.ld;
-    if ((int64_t)bx * 64 >= nc) return;
+    __shared__ double sx[2 * SRK_MAX_SEPW];
+    __shared__ double sp[4][64];
+    const int c = blockIdx.z;
+    const int64_t nc = B.it[c].ncols, ldc = B.it[c].ld;
+    if ((int64_t)blockIdx.x * 64 >= nc) return;
     const int64_t top_sep = c > 0 ? c - 1 : -1, bot_sep = c < P - 1 ? c : -1;
-    if (bx == 0 && bot_sep >= 0)
+    if (blockIdx.x == 0 && bot_sep >= 0)
         for (int64_t u = threadIdx.x; u < sepw; u += 256) {
             const double v = xs[bot_sep * sepw + u];
-            bwd_store<WT>(x + sep_start[bot_sep] + u, v);
+            x[sep_start[bot_sep] + u] = v;
             if (finite && !isfinite(v)) atomicOr(finite, 4);
         }
     for (int64_t u2 = threadIdx.x; u2 < 2 * sepw; u2 += 256) {
@@ -1461,119 +1420,19 @@ __device__ __forceinline__ void bwd_border_body(const CholItem& it, int c, int b
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t j = (int64_t)bx * 64 + lane; // nc is a multiple of 64
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane; // nc is a multiple of 64
     const int64_t rows = (2 * sepw) / 4, u0 = wave * rows;
-    const double* col = it.A + (nc + u0) * ldc + j;
+    const double* col = B.it[c].A + (nc + u0) * ldc + j;
     double acc = 0;
 #pragma unroll 8
     for (int64_t u2 = 0; u2 < rows; ++u2) acc = fma(col[u2 * ldc], sx[u0 + u2], acc);
     sp[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0) bwd_store<WT>(it.y + j, it.y[j] - ((sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane])));
-}
-__global__ __launch_bounds__(256) void k_bwd_border(const CholBatch B, int P, int64_t sepw, const double* __restrict__ xs,
-                                                    const int64_t* __restrict__ sep_start, double* __restrict__ x,
-                                                    int* __restrict__ finite)
-{
-    __shared__ double sx[2 * SRK_MAX_SEPW];
-    __shared__ double sp[4][64];
-    bwd_border_body<false>(B.it[blockIdx.z], (int)blockIdx.z, (int)blockIdx.x, P, sepw, xs, sep_start, x, finite, sx, sp);
-}
-
-// ---------------------------------------------------------------- the whole backward substitution as ONE launch
-// The backward substitution of a nested solve is a chain of small dependent steps -- per level the fold of the separator
-// solution into the chunks' right-hand sides, then one step per 256-column panel (C3: ten launches of ~9.5 us, each three
-// dependent memory round trips of work).  k_bwd_all runs the same steps, same bodies, in one launch: the host hands it the
-// list of steps (BwdPhase, built once per plan and kept on the device), every workgroup walks the list and takes its share
-// of each step, and a grid barrier separates the steps.  The barrier follows the hand-off recipe of k_step256 (the guide's
-// Guideline 16 R1): what a step publishes leaves by write-through stores, every wave drains, workgroup barrier, one lane adds
-// to a monotonic device counter (never reset: the host knows the value every launch starts from); the waiting side polls
-// from one lane, ONE agent-scope acquire, workgroup barrier, plain loads.  Spins are bounded like k_step256's: a timeout
-// sets bit 8 of *info and the host repeats the solve with the stand-alone launches.  All workgroups of the launch must be
-// resident together (the host keeps the grid within SRK_BWD_ALL_MAX_WGS; other kernels in flight are finite).
-struct BwdPhase {
-    int32_t type;      // 0: a 256-column panel step of every item (k_bwd256), 1: the border fold of a level (k_bwd_border)
-    int32_t n_items, bx, P, check_finite, pad_;
-    int64_t sepw;
-    const double* xs;
-    const int64_t* sep_start;
-    double* x;
-    CholItem it[SRK_MAX_CHUNKS];
-    int64_t K[SRK_MAX_CHUNKS], cbeg[SRK_MAX_CHUNKS];
-};
-#define SRK_BWD_ALL_MAX_WGS 1024
-__global__ __launch_bounds__(256) void k_bwd_all(const BwdPhase* __restrict__ ph, int n_phases, unsigned* __restrict__ bar,
-                                                 unsigned bar_base, int* __restrict__ info)
-{
-    __shared__ double sx[2 * SRK_MAX_SEPW];
-    __shared__ double spb[4][NBO - NB];
-    const int w = blockIdx.x;
-    for (int p = 0; p < n_phases; ++p) {
-        const BwdPhase& P = ph[p];
-        if (w < P.bx * P.n_items) {
-            const int z = w / P.bx, bx = w - z * P.bx;
-            if (P.type == 0)
-                bwd256_body<true>(P.it[z], P.K[z], P.cbeg[z], bx, P.check_finite ? info : nullptr, sx, spb);
-            else
-                bwd_border_body<true>(P.it[z], z, bx, P.P, P.sepw, P.xs, P.sep_start, P.x, P.check_finite ? info : nullptr, sx,
-                                      reinterpret_cast<double (*)[64]>(&spb[0][0]));
-        }
-        if (p + 1 == n_phases) break;
-        // ---- grid barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = bar_base + (unsigned)(p + 1) * gridDim.x;
-            int spins = 0;
-            while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                if (++spins > ST_SPIN_MAX * 8 ||
-                    ((spins & 63) == 0 && (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8))) {
-                    atomicOr(info, 8);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(ST_POLL_SLEEP);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
-}
-
-static void record_bwd256(BwdRecorder* rec, const CholBatch& B, int n, const CholStep& Kst, const CholStep& cbeg, int64_t blocks,
-                          bool check_finite)
-{
-    BwdPhase ph;
-    std::memset(&ph, 0, sizeof ph);
-    ph.type = 0;
-    ph.n_items = n;
-    ph.bx = (int32_t)blocks;
-    ph.check_finite = check_finite ? 1 : 0;
-    for (int i = 0; i < n; ++i) ph.it[i] = B.it[i], ph.K[i] = Kst.v[i], ph.cbeg[i] = cbeg.v[i];
-    rec->phases->push_back(ph);
-}
-static void record_border(BwdRecorder* rec, const CholBatch& B, int P, int64_t sepw, const double* xs, const int64_t* sep_start,
-                          double* x, int64_t blocks, bool check_finite)
-{
-    BwdPhase ph;
-    std::memset(&ph, 0, sizeof ph);
-    ph.type = 1;
-    ph.n_items = P;
-    ph.bx = (int32_t)blocks;
-    ph.P = P;
-    ph.check_finite = check_finite ? 1 : 0;
-    ph.sepw = sepw;
-    ph.xs = xs;
-    ph.sep_start = sep_start;
-    ph.x = x;
-    for (int i = 0; i < P; ++i) ph.it[i] = B.it[i];
-    rec->phases->push_back(ph);
+    if (wave == 0) B.it[c].y[j] -= (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
 }
 
 static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs, double* x,
-                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, bool top, SrkCholSync* sync,
-                          BwdRecorder* rec)
+                          const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, bool top, SrkCholSync* sync)
 {
     const int P = pl.P;
     const int64_t sepw = pl.sepw, lds = pl.lds;
@@ -1606,80 +1465,20 @@ static void solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, con
     chol_factor(s, B, P, H, d_info, prof, sync);
     LAUNCH(k_sep_reduce, dim3((unsigned)lds), dim3(256), 0, s, B, sepw, pl.Cs, lds, pl.ws);
     if (pl.child) { // the separator system is block tridiagonal: chunk it again
-        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof, false, sync, rec);
+        solve_chunked(s, *pl.child, lds, pl.Cs, pl.ws, pl.xs, pl.d_sep_env, d_info, prof, false, sync);
     } else {
         chol_factor(s, Bs, 1, &Hs, d_info, prof, sync);
-        chol_bwd(s, Bs, 1, &Hs, prof, nullptr, rec);
+        chol_bwd(s, Bs, 1, &Hs, prof, nullptr);
     }
     int* d_finite = top ? d_info : nullptr;
-    if (rec) record_border(rec, B, P, sepw, pl.xs, pl.d_sep_start, x, max_nc / 64, d_finite != nullptr);
-    else LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs, pl.d_sep_start, x,
-                d_finite);
-    chol_bwd(s, B, P, H, prof, d_finite, rec);
+    LAUNCH(k_bwd_border, dim3((unsigned)(max_nc / 64), 1, (unsigned)P), dim3(256), 0, s, B, P, sepw, pl.xs, pl.d_sep_start, x,
+           d_finite);
+    chol_bwd(s, B, P, H, prof, d_finite);
 }
 
 void srk_chol_solve_chunked(hipStream_t s, const SrkChunkPlan& pl, int64_t ld, const double* S, const double* rhs,
                             double* x, const int64_t* d_env_col, int* d_info, SrkSolveProf* prof, SrkCholSync* sync)
 {
     // every variable of the system is a chunk or a separator variable of the top level: its backward kernels check them all
-    const bool fuse_bwd = sync && sync->flags && sync->fused && !(prof && prof->dry);
-    if (!fuse_bwd) {
-        solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true, sync, nullptr);
-        return;
-    }
-    // forward part launched as it goes, the backward steps recorded, then run as ONE launch (k_bwd_all)
-    std::vector<BwdPhase> phases;
-    BwdRecorder rec{ &phases };
-    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true, sync, &rec);
-    int64_t grid = 1;
-    for (const BwdPhase& ph : phases) grid = std::max<int64_t>(grid, (int64_t)ph.bx * ph.n_items);
-    const size_t bytes = phases.size() * sizeof(BwdPhase);
-    bool ok = grid <= SRK_BWD_ALL_MAX_WGS && !phases.empty();
-    if (ok && (sync->h_bwd.size() != bytes || std::memcmp(sync->h_bwd.data(), phases.data(), bytes) != 0)) {
-        // (first solve of this plan on this slot, or the plan changed: the list goes to the device once)
-        if (sync->d_bwd_bytes < bytes) {
-            if (sync->d_bwd) (void)hipFree(sync->d_bwd);
-            sync->d_bwd = nullptr;
-            sync->d_bwd_bytes = 0;
-            if (hipMalloc(&sync->d_bwd, bytes) == hipSuccess) sync->d_bwd_bytes = bytes;
-            else ok = false;
-        }
-        if (ok) {
-            // the stream may still run a launch that reads the old list
-            (void)hipStreamSynchronize(s);
-            sync->h_bwd.assign(reinterpret_cast<const char*>(phases.data()), reinterpret_cast<const char*>(phases.data()) + bytes);
-            ok = hipMemcpy(sync->d_bwd, sync->h_bwd.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
-            if (!ok) sync->h_bwd.clear();
-        }
-    }
-    if (ok) {
-        hipLaunchKernelGGL(k_bwd_all, dim3((unsigned)grid), dim3(256), 0, s, reinterpret_cast<const BwdPhase*>(sync->d_bwd),
-                           (int)phases.size(), sync->flags + SRK_SYNC_BAR, sync->bar_count, d_info);
-        sync->bar_count += (unsigned)grid * (unsigned)(phases.size() - 1);
-        return;
-    }
-    // too wide for one resident grid (or no memory for the list): the recorded steps as stand-alone launches
-    for (const BwdPhase& ph : phases) {
-        CholBatch B{};
-        for (int i = 0; i < ph.n_items; ++i) B.it[i] = ph.it[i];
-        int* fin = ph.check_finite ? d_info : nullptr;
-        if (ph.type == 0) {
-            CholStep Kst, cbeg;
-            for (int i = 0; i < SRK_MAX_CHUNKS; ++i) Kst.v[i] = i < ph.n_items ? ph.K[i] : -1, cbeg.v[i] = i < ph.n_items ? ph.cbeg[i] : 0;
-            hipLaunchKernelGGL(k_bwd256, dim3((unsigned)ph.bx, 1, (unsigned)ph.n_items), dim3(256), 0, s, B, Kst, cbeg, fin);
-        } else {
-            hipLaunchKernelGGL(k_bwd_border, dim3((unsigned)ph.bx, 1, (unsigned)ph.P), dim3(256), 0, s, B, ph.P, ph.sepw, ph.xs,
-                               ph.sep_start, ph.x, fin);
-        }
-    }
-}
-
-void srk_chol_sync_free(SrkCholSync* sync)
-{
-    if (sync && sync->d_bwd) (void)hipFree(sync->d_bwd);
-    if (sync) {
-        sync->d_bwd = nullptr;
-        sync->d_bwd_bytes = 0;
-        sync->h_bwd.clear();
-    }
+    solve_chunked(s, pl, ld, S, rhs, x, d_env_col, d_info, prof, true, sync);
 }

@@ -144,21 +144,12 @@ struct SrkSolveProf {
 
 // state of the fused outer-step kernel's in-launch hand-offs (k_step256): flag words (device, zeroed once, 16 per batch
 // item) that hold the epoch of the launch that set them, and the host's launch counter.  One per stream.
-#define SRK_SYNC_WORDS (16 * 32 + 16) // 16 words x SRK_MAX_CHUNKS items, then the grid-barrier counter of k_bwd_all
-#define SRK_SYNC_BAR (16 * 32)
+#define SRK_SYNC_WORDS (16 * 32) // 16 words x SRK_MAX_CHUNKS items
 struct SrkCholSync {
     unsigned* flags = nullptr;
     unsigned epoch = 0;
-    bool fused = true; // false: the unfused k_panel / k_upd64 sequence and the stand-alone backward launches
-    // k_bwd_all (the backward substitution of a nested solve as one launch): the step list lives on the device, built at
-    // the first solve of a plan and reused while the host-side copy still matches; bar_count = value of the barrier
-    // counter flags[SRK_SYNC_BAR] when the next launch starts
-    void* d_bwd = nullptr;
-    size_t d_bwd_bytes = 0;
-    std::vector<char> h_bwd;
-    unsigned bar_count = 0;
+    bool fused = true; // false: the unfused k_panel / k_upd64 sequence
 };
-void srk_chol_sync_free(SrkCholSync* sync); // releases d_bwd
 
 // ---- dense SPD solver (srk_chol.hip) ----
 // In-place blocked Cholesky of the lower triangle of A (row-major, ld x ld, ld % SRK_CHOL_NB == 0) with the forward
