@@ -1041,7 +1041,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     const bool multi_upload = h->allreduce || h->comm;
     const int n_slots = (multi_upload && h->dp_schedule && (h->world >= 2 || h->dp_force))
                             ? (h->dp_force ? SRK_SLOTS : std::min(SRK_SLOTS, h->world))
-                            : (h->speculate ? (multi_upload ? 2 : SRK_SLOTS) : 1);
+                            : (h->speculate ? 2 : 1);
     for (int w = 0; w < SRK_SLOTS + 1; ++w) {
         if (w > n_slots) continue;
         ALLOC(h->pts[w], 24 * N);
@@ -1847,11 +1847,12 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             // usually is the last one: it runs alone unless the previous iteration needed four or more (then the damping
             // factor has a long way to climb and pairs pay again)
             const bool pair_pays = round == 0 ? (spec_wanted || rep->iterations >= 1) : (round >= 2 || prev_attempts >= 4);
-            // (round 3) a TRIPLE when the previous iteration needed three attempts or more: late in a run on the circle-grid
-            // scenes almost every iteration rejects c / 10 and c and accepts 10 c -- a pair plus a lone third attempt then
-            // paid two solve chains in sequence (3.3 ms); three Schur sums back to back and three solves side by side do not
-            int want = 1;
-            if (can_speculate && pair_pays) want = (round == 0 && prev_attempts >= 3 && h->att[2].allocated && !multi) ? 3 : 2;
+            // (Round 3, measured and dropped: TRIPLES when the previous iteration needed three attempts -- late in a run on
+            // the circle-grid scenes 16 of 20 iterations reject c / 10 and c and accept 10 c.  Three solves side by side are
+            // slower than a pair plus a lone attempt, 299-302 against 331 it/s: one solve's fused outer steps hold ~200
+            // workgroups of 66 KB LDS, two solves fill the chip's LDS, the third waits for slots.  Holding the solves back
+            // until the last Schur sum is done: 325 against 331 it/s with pairs, 283-299 with triples.)
+            const int want = (can_speculate && pair_pays) ? 2 : 1;
             int n_now = 1; // attempts enqueued this round: the factors hessian_factor * 10^k that the cap allows
             for (double cc = hessian_factor * 10; n_now < want && !(max_hessian_factor && cc > *max_hessian_factor); cc *= 10) ++n_now;
             const bool speculate_now = n_now >= 2;
