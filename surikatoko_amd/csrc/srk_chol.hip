@@ -92,12 +92,27 @@ __device__ __forceinline__ double fast_rsqrt(double d)
 //      y_c for its column-rows c and applies the rank-4 update a_ic -= sum_k l_ik y_ck.
 // The slot of the NEXT group is updated and published first, so its barrier round trip hides under the other updates.
 // Entries above the diagonal are updated too (never read): no per-element predicates.
-__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][64][4]: panel P, finals Y*/,
+// (round 3) The rank-4 update of the slots behind the next one used to sit between the next panel's publication and its
+// barrier: every wave reached that barrier ~200 cycles (on average) later than the panel needed.  Those updates are now
+// DEFERRED behind the barrier and issued among the dependent instructions of the next group's 4 x 4 factorisation (independent
+// work for that latency-bound chain); the finals Y are double-buffered for it.  Every entry still receives the groups'
+// updates in the same order with the same operands: results are bit-identical to the former order.
+// The reciprocals of the 4 x 4 factor take ONE Newton step on the v_rcp_f64 seed (tools/ubench/rcp_acc.hip: relative error
+// after one step <= 2 ulp): they only scale multipliers, a relative error of 1e-16 there is one more rounding of an entry of L;
+// everything a hand-off partner recomputes (1 / L_tt of the stored factor) keeps the two-step reciprocal.
+__device__ __forceinline__ double fast_rcp1(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+#ifndef SRK_POTRF_RCP
+#define SRK_POTRF_RCP fast_rcp1
+#endif
+__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][64][4]: panel P, finals Y (two buffers)*/,
                                         double* sDiag /*[64]*/, double* sInv /*[64]*/)
 {
     const int t = threadIdx.x, i = t >> 2, q = t & 3;
     double (*sP)[4] = reinterpret_cast<double (*)[4]>(sPY);
-    double (*sY)[4] = reinterpret_cast<double (*)[4]>(sPY + 4 * NB);
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = sD[i][4 * m + q];
@@ -106,25 +121,37 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
     double dmin = 1.0, dchk = 0.0;
     sP[i][q] = a[0];
     lds_barrier();
+    double zp0 = 0, zp1 = 0, zp2 = 0, zp3 = 0; // multipliers of the previous group: its deferred updates
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
+        double (*sY)[4] = reinterpret_cast<double (*)[4]>(sPY + 4 * NB * (1 + (g & 1)));      // finals of this group
         // ---- A: the 4 x 4 diagonal block of the group (rows 4g .. 4g+3 of the panel), LDL^T with unscaled entries
         const double2* Dp = reinterpret_cast<const double2*>(&sP[4 * g][0]);
         const double2 d0 = Dp[0], d1 = Dp[2], d2a = Dp[4], d2b = Dp[5], d3a = Dp[6], d3b = Dp[7];
+        // ---- the previous group's rank-4 update of the slots behind this one (deferred: independent of the chain below)
+        if (g > 0) {
+            double (*sYp)[4] = reinterpret_cast<double (*)[4]>(sPY + 4 * NB * (1 + ((g - 1) & 1)));
+#pragma unroll
+            for (int m = g + 1; m < 16; ++m) {
+                const double2* yp = reinterpret_cast<const double2*>(&sYp[4 * m + q][0]);
+                const double2 y01 = yp[0], y23 = yp[1];
+                a[m] = fma(-zp3, y23.y, fma(-zp2, y23.x, fma(-zp1, y01.y, fma(-zp0, y01.x, a[m]))));
+            }
+        }
         const double u00 = d0.x;
-        const double r0 = fast_rcp(u00);
+        const double r0 = SRK_POTRF_RCP(u00);
         const double u10 = d1.x, u20 = d2a.x, u30 = d3a.x;
         const double l10 = u10 * r0, l20 = u20 * r0, l30 = u30 * r0;
         const double u11 = fma(-l10, u10, d1.y);
-        const double r1 = fast_rcp(u11);
+        const double r1 = SRK_POTRF_RCP(u11);
         const double u21 = fma(-l20, u10, d2a.y), u31 = fma(-l30, u10, d3a.y);
         const double l21 = u21 * r1, l31 = u31 * r1;
         const double u22 = fma(-l21, u21, fma(-l20, u20, d2b.x));
-        const double r2 = fast_rcp(u22);
+        const double r2 = SRK_POTRF_RCP(u22);
         const double u32 = fma(-l31, u21, fma(-l30, u20, d3b.x));
         const double l32 = u32 * r2;
         const double u33 = fma(-l32, u32, fma(-l31, u31, fma(-l30, u30, d3b.y)));
-        const double r3 = fast_rcp(u33);
+        const double r3 = SRK_POTRF_RCP(u33);
         dmin = fmin(fmin(dmin, u00), fmin(u11, fmin(u22, u33)));
         dchk = fma(0.0, u00, fma(0.0, u11, fma(0.0, u22, fma(0.0, u33, dchk))));
         // ---- B: this row against the factor.  y_k = p_k - sum_{k' < k} (y_k' / d_k') u_kk'
@@ -140,21 +167,15 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[2][
         if (g == 15) break;
         sY[i][q] = a[g];
         lds_barrier();
-        // the next group's slot first: update, publish, barrier -- the remaining slots follow under that latency
+        // the next group's slot: update, publish, barrier -- the remaining slots follow behind that barrier (above)
         {
             const double2* yp = reinterpret_cast<const double2*>(&sY[4 * (g + 1) + q][0]);
             const double2 y01 = yp[0], y23 = yp[1];
             a[g + 1] = fma(-z3, y23.y, fma(-z2, y23.x, fma(-z1, y01.y, fma(-z0, y01.x, a[g + 1]))));
             sP[i][q] = a[g + 1];
         }
-#pragma unroll
-        for (int m = g + 2; m < 16; ++m) {
-            const double2* yp = reinterpret_cast<const double2*>(&sY[4 * m + q][0]);
-            const double2 y01 = yp[0], y23 = yp[1];
-            a[m] = fma(-z3, y23.y, fma(-z2, y23.x, fma(-z1, y01.y, fma(-z0, y01.x, a[m]))));
-            if (((m - g) & 3) == 1) asm volatile("" ::: "memory"); // keep <= 8 sixteen-byte reads in flight
-        }
-        lds_barrier(); // panel of group g + 1 is complete (and every read of sY is done)
+        zp0 = z0; zp1 = z1; zp2 = z2; zp3 = z3;
+        lds_barrier(); // panel of group g + 1 is complete
     }
     // the owner of a diagonal entry holds its pivot d_i
 #pragma unroll
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
     __shared__ double sZ[NB][NB + 1]; // inverse workgroup only
     __shared__ double sT[32][33];
-    __shared__ __attribute__((aligned(16))) double sCol[8 * NB]; // potrf64: panel [64][4] + finals [64][4]
+    __shared__ __attribute__((aligned(16))) double sCol[12 * NB]; // potrf64: panel [64][4] + finals 2 x [64][4]
     __shared__ double sDiag[NB];
     __shared__ double sInv[NB];
     __shared__ double sy[NB];
@@ -638,12 +659,17 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
     const int role = blockIdx.x, tid = threadIdx.x;
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
     __shared__ __attribute__((aligned(16))) double sA[NB][NB + 2]; // own X of this sub-step (MFMA A operand); inverse role: sZ
-    __shared__ double sT[32][33];                                  // inverse role only
-    __shared__ __attribute__((aligned(16))) double sCol[8 * NB];
+    // One region for the role-specific scratch: the inverse role's sT, or the other roles' potrf panel / finals, sInv and sy.
+    // (Round 3: with separate arrays the kernel held 83.7 KB of LDS -- 3 KB too much for TWO workgroups on a CU's 160 KB, so
+    // the ~416 workgroups of a speculative pair's two solves took turns on the 256 CUs instead of running side by side.)
+    __shared__ __attribute__((aligned(16))) double sU[32 * 33 > 14 * NB ? 32 * 33 : 14 * NB];
     __shared__ double sDiag[NB];
-    __shared__ double sInv[NB];
-    __shared__ double sy[NB];
+    double (*sT)[33] = reinterpret_cast<double (*)[33]>(sU);   // inverse role only
+    double* sCol = sU;                                         // [12 NB] potrf64: panel + two buffers of finals
+    double* sInv = sU + 12 * NB;                               // [NB]
+    double* sy = sU + 13 * NB;                                 // [NB]
     static_assert(sizeof(double) * NB * (NB + 2) >= sizeof(double) * NB * (NB + 1), "sZ fits sA");
+    static_assert(2 * (2 * sizeof(double) * NB * (NB + 2) + sizeof(sU) + sizeof(double) * NB) <= 160 * 1024, "two workgroups per CU");
     if (role == 4) { // ---- inverses of the diagonal tiles, as they are published
         for (int d = 0; d < NBO / NB; ++d) {
             st_wait(fl, 1u << ST_F(d), epoch, info);
@@ -1062,6 +1088,75 @@ __global__ __launch_bounds__(256) void k_trail64(const CholBatch B, const CholSt
             for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
 }
 
+// ---------------------------------------------------------------- trailing update, few-tiles variant
+// The same contraction on 32 x 32 tiles, one 16 x 16 MFMA tile per wave.  At the deeper levels of a nested solve only the
+// 512 x 512 border block of two to eight chunks is updated: 36 tile pairs of 64 x 64 a chunk leave most of the chip idle
+// while every workgroup works through 256 MFMAs per wave (7.8 us) behind four dependent K chunks of loads (k_trail64:
+// 19-31 us a launch there).  Here a workgroup has a quarter of that work, and ALL four K chunks of its operands are
+// requested up front (one memory round trip: 128 registers of loads in flight).  Same products in the same order per entry
+// of C as k_trail64 (chunks ascending, k ascending inside): bit-identical results.
+#define NT 32
+__global__ __launch_bounds__(256) void k_trail32(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                  int64_t k0, int64_t c_first)
+{
+    __shared__ double sA[NT][LDSP];
+    __shared__ double sB[NT][LDSP];
+    if (rend.v[blockIdx.z] < 0) return;
+    double* __restrict__ A = B.it[blockIdx.z].A;
+    const int64_t ld = B.it[blockIdx.z].ld, r2_begin = r2b.v[blockIdx.z];
+    int64_t T1 = (rend.v[blockIdx.z] - c_first) / NT;
+    if (T1 < 0) T1 = 0;
+    int64_t p = blockIdx.x;
+    {
+        const int64_t T = T1 + (r2e.v[blockIdx.z] - r2_begin) / NT;
+        if (p >= T * (T + 1) / 2) return;
+    }
+    int ti = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(ti + 1) * (ti + 2) / 2 <= p) ++ti;
+    while ((int64_t)ti * (ti + 1) / 2 > p) --ti;
+    int tj = (int)(p - (int64_t)ti * (ti + 1) / 2);
+    const int64_t r0 = ti < T1 ? c_first + (int64_t)ti * NT : r2_begin + ((int64_t)ti - T1) * NT;
+    const int64_t c0 = tj < T1 ? c_first + (int64_t)tj * NT : r2_begin + ((int64_t)tj - T1) * NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    // staging map of a 64-deep K chunk: thread -> row (t >> 3) of 32, eight doubles from column 8 (t & 7)
+    const int row = threadIdx.x >> 3, seg = (threadIdx.x & 7) * 8;
+    const double* pa = A + (r0 + row) * ld + k0 + seg;
+    const double* pb = A + (c0 + row) * ld + k0 + seg;
+    double2 va[NBO / NB][4], vb[NBO / NB][4];
+#pragma unroll
+    for (int ch = 0; ch < NBO / NB; ++ch)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            va[ch][t] = reinterpret_cast<const double2*>(pa + ch * NB)[t];
+            vb[ch][t] = reinterpret_cast<const double2*>(pb + ch * NB)[t];
+        }
+    // the C tile is read-modify-write: f64 16x16x4 accumulator map col = lane & 15, row = (lane >> 4) + 4 reg
+    double* pc0 = A + (r0 + wr * 16 + lk) * ld + c0 + wc * 16 + lr;
+    double cv[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cv[reg] = pc0[(int64_t)(4 * reg) * ld];
+    double4_t acc = (double4_t){ 0, 0, 0, 0 };
+#pragma unroll
+    for (int ch = 0; ch < NBO / NB; ++ch) {
+        if (ch) __syncthreads(); // previous chunk fully consumed
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sA[row][seg + 2 * t] = va[ch][t].x;
+            sA[row][seg + 2 * t + 1] = va[ch][t].y;
+            sB[row][seg + 2 * t] = vb[ch][t].x;
+            sB[row][seg + 2 * t + 1] = vb[ch][t].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[wr * 16 + lr][kk * 4 + lk], sB[wc * 16 + lr][kk * 4 + lk], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(4 * reg) * ld] = cv[reg] - acc[reg];
+}
+
 // ---------------------------------------------------------------- backward substitution L^T x = y
 // (the inverses of the diagonal tiles come from the inverse workgroup of k_panel)
 // step K (descending, 256 rows): x_K = L_KK^-T y_K by four tile back-substitutions with the explicit tile inverses
@@ -1221,7 +1316,13 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
         const bool timed = prof && !prof->dry && T > 0 && 2 * prof->n + 1 < prof->cap;
         if (prof && T > 0) prof->flops += flops;
         if (timed) hipEventRecord(prof->ev[2 * prof->n], s);
-        if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
+        int n_live = 0;
+        for (int i = 0; i < n; ++i) n_live += st.v[i] >= 0 ? 1 : 0;
+        if (T > 0 && T <= 4 && (int64_t)n_live * (2 * T) * (2 * T + 1) / 2 <= 320) { // a few small blocks: 32x32 tiles, 16x the workgroups
+            const int64_t T32 = 4 * T;
+            LAUNCH(k_trail32, dim3((unsigned)(T32 * (T32 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, k0,
+                               c_first);
+        } else if (T > 0 && T <= 8) { // narrow skyline: 64x64 tiles, 4x the workgroups
             const int64_t T64 = 2 * T;
             LAUNCH(k_trail64, dim3((unsigned)(T64 * (T64 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, k0,
                                c_first);
