@@ -780,7 +780,8 @@ __device__ __forceinline__ bool point_block_inverse(const double* __restrict__ V
 
 // The same block as a Cholesky factor E = L L^T, for the SYRK form of the Schur sum (k_schur_mm on uniform runs):
 //     W^T E^-1 W = Z^T Z,  Z = L^-1 W,      W^T E^-1 g = Z^T (L^-1 g).
-// Lc = { 1/l00, l10, 1/l11, l20, l21, 1/l22 }, h = L^-1 g.  Returns 0: |det| <= 1e-12, the landmark is skipped exactly as
+// Lc = the lower triangle of L^-1 by rows { I00, I10, I11, I20, I21, I22 } (so that every row of Z = L^-1 W is three
+// multiply-adds on its own), h = L^-1 g.  Returns 0: |det| <= 1e-12, the landmark is skipped exactly as
 // with the inverse (:1877-1881); 1: factor formed; 2: the block passes the determinant check but a pivot is not positive
 // (E = V + c diag(V) with V a sum of outer products is positive definite in exact arithmetic, so this needs a damping
 // factor below the rounding level of V) -- the caller hands such a landmark to the per-landmark inverse path, so the sum
@@ -804,10 +805,12 @@ __device__ __forceinline__ int point_block_cholesky(const double* __restrict__ V
     const double d2 = e22 - l20 * l20 - l21 * l21;
     const double l22 = sqrt(d2), i2 = 1 / l22;
     if (!(e00 > 0 && d1 > 0 && d2 > 0) || !isfinite(i0) || !isfinite(i1) || !isfinite(i2)) return 2;
-    Lc[0] = i0; Lc[1] = l10; Lc[2] = i1; Lc[3] = l20; Lc[4] = l21; Lc[5] = i2;
-    h[0] = g0 * i0;
-    h[1] = (g1 - l10 * h[0]) * i1;
-    h[2] = (g2 - l20 * h[0] - l21 * h[1]) * i2;
+    const double I10 = -l10 * i0 * i1, I21 = -l21 * i1 * i2;
+    const double I20 = -(l20 * i0 + l21 * I10) * i2;
+    Lc[0] = i0; Lc[1] = I10; Lc[2] = i1; Lc[3] = I20; Lc[4] = I21; Lc[5] = i2;
+    h[0] = i0 * g0;
+    h[1] = I10 * g0 + i1 * g1;
+    h[2] = I20 * g0 + I21 * g1 + i2 * g2;
     return 1;
 }
 
@@ -1660,7 +1663,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         }
         if (tid < np && !ragged) {
             // uniform runs take the SYRK form: E = L L^T, the helpers stage Z = L^-1 W alone and both MFMA operands read
-            // it (sum W^T E^-1 W = Z^T Z).  sE row: 1/l00 l10 1/l11 l20 l21 1/l22 | L^-1 g.  A skipped landmark (|det| <=
+            // it (sum W^T E^-1 W = Z^T Z).  sE row: the lower triangle of L^-1 by rows | L^-1 g.  A skipped landmark (|det| <=
             // 1e-12) stages zeros; one whose block passes that check but has no positive pivots stages zeros as well and is
             // handed back (irr) to the per-landmark inverse path, which k_assemble's tail workgroups run.
             double Lc[6], hh[3];
@@ -1790,7 +1793,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (ypl < nb) {
                 const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]);
                 const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
-                const double i0 = e01.x, l10 = e01.y, i1 = e23.x, l20 = e23.y, l21 = e45.x, i2 = e45.y;
+                const double I00 = e01.x, I10 = e01.y, I11 = e23.x, I20 = e23.y, I21 = e45.x, I22 = e45.y;
                 double w[NC][3];
                 int cc[NC];
 #pragma unroll
@@ -1805,9 +1808,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 for (int i = 0; i < NC; ++i) {
                     const int col = lane + 64 * i;
                     double* wp = bw + 3 * ypl * LDW + cc[i];
-                    const double z0 = w[i][0] * i0;
-                    const double z1 = (w[i][1] - l10 * z0) * i1;
-                    const double z2 = (w[i][2] - l20 * z0 - l21 * z1) * i2;
+                    const double z0 = I00 * w[i][0];
+                    const double z1 = I10 * w[i][0] + I11 * w[i][1];
+                    const double z2 = I20 * w[i][0] + I21 * w[i][1] + I22 * w[i][2];
                     wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
                     const double rr = z0 * e67.x + z1 * e67.y + z2 * e89.x;
                     racc[i] += col < nf10 ? rr : 0.0;
@@ -1828,30 +1831,40 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int pl2 = q2 / nf, a2 = q2 - pl2 * nf;
         const int dst2 = 3 * pl2 * LDW + 10 * a2;
         double pre2[NBT][3], racc2[NBT];
-        double fap[3], fbp[3]; // fp64 storage: the observation's point-side factors; pre2[b][0 / 1] = Af / Bf of column b
 #pragma unroll
         for (int b = 0; b < NBT; ++b) racc2[b] = 0;
         int nq2 = 0;
+        // ---- fp64 storage (the rank-2 factors): lane h = QMAX m + q takes ROW m (point coordinate) of observation q,
+        //     z[m][:] = (L^-1 Ap)[m] Af[:] + (L^-1 Bp)[m] Bf[:],   (L^-1 Ap)[m] = row m of L^-1 (from sE) . Ap.
+        // Why rows: in-kernel stamps had the multiplying waves through a round's MFMAs after 2.0 us and then 1.3 us at the
+        // barrier -- waiting for the HELPERS, whose vector-ALU instructions only issue in the gaps of their SIMD's three MFMA
+        // streams (about one per MFMA slot, tools/ubench/mfma64_side.hip): what a round costs them is their instruction
+        // count.  The column split above (each lane the three coordinates of four columns) needed ~90 vector-ALU
+        // instructions a round -- the substitution for all three rows in every lane, 64-bit address arithmetic for its
+        // lane-dependent factor planes, twelve 8-byte LDS writes; a row needs three multiply-adds for its two scalars, two for
+        // each of its ten entries, every plane base is wave-uniform (one 32-bit lane offset for all 21 loads) and its ten
+        // entries leave as five 16-byte LDS writes: ~40.
+        const int sm3 = h / QMAX, sq3 = h - sm3 * QMAX;
+        const int pl3 = sq3 / nf, a3 = sq3 - pl3 * nf;
+        const int dst3 = (3 * pl3 + sm3) * LDW + 10 * a3;
+        double f3[SRK_WF_PLANES], racc3[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) racc3[i] = 0;
         auto load_round2 = [&](int r) {
             const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
+            if constexpr (WStore<WT>::factored) {
+                nq2 = sm3 < 3 ? rb - ra : 0;
+                if (sq3 < nq2) {
+                    const unsigned voff = (unsigned)(o0 + ra + sq3);
+#pragma unroll
+                    for (int k = 0; k < SRK_WF_PLANES; ++k) {
+                        const WT* sb = W + (int64_t)k * d.Os; // wave-uniform plane base
+                        f3[k] = sb[voff];
+                    }
+                }
+            } else {
             nq2 = i02 < 3 ? rb - ra : 0;
             if (q2 < nq2) {
-                if constexpr (WStore<WT>::factored) {
-                    const WT* wo = W + (o0 + ra + q2);
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        fap[m] = wo[(int64_t)(SRK_WF_AP + m) * d.Os];
-                        fbp[m] = wo[(int64_t)(SRK_WF_BP + m) * d.Os];
-                    }
-#pragma unroll
-                    for (int b = 0; b < NBT; ++b) {
-                        if (i02 + 3 * b < 10) { // (planes of the frame-side factors of column i02 + 3 b; -1: structurally zero)
-                            const int pa = srk_wf_af_plane(i02 + 3 * b), pb = srk_wf_bf_plane(i02 + 3 * b);
-                            pre2[b][0] = pa >= 0 ? wo[(int64_t)pa * d.Os] : 0.0;
-                            pre2[b][1] = pb >= 0 ? wo[(int64_t)pb * d.Os] : 0.0;
-                        }
-                    }
-                } else {
                 // plane base (wave-uniform: scalar registers) + one 32-bit lane offset: no 64-bit address arithmetic per load
                 const unsigned voff = (unsigned)(o0 + ra + q2) + (unsigned)i02 * (unsigned)d.Os;
 #pragma unroll
@@ -1864,48 +1877,51 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                         }
                     }
                 }
-                }
+            }
             }
         };
-        // (round 3: the SYRK form -- the lane forms z = L^-1 w for its columns, a 3 x 3 forward substitution on the registers
-        // it already holds, and stages that ONE array: half the LDS writes of the W + Y form, six multiply-adds instead of nine)
+        // (round 3: the SYRK form -- Z = L^-1 W is the ONE staged array: half the LDS writes of the W + Y form)
         auto stage_round2 = [&](int r, double* bw) {
             const int pb = r * PB;
             const int nb = np - pb < PB ? np - pb : PB;
+            if constexpr (WStore<WT>::factored) {
+                if (sq3 < nq2) {
+                    const double* E = sE[pb + pl3];
+                    const int r3 = sm3 * (sm3 + 1) / 2; // row sm3 of the lower triangle of L^-1: 1, 2 or 3 entries
+                    const double li0 = E[r3], li1 = sm3 >= 1 ? E[r3 + 1] : 0.0, li2 = sm3 >= 2 ? E[r3 + 2] : 0.0, hm = E[6 + sm3];
+                    const double am = li0 * f3[SRK_WF_AP] + li1 * f3[SRK_WF_AP + 1] + li2 * f3[SRK_WF_AP + 2];
+                    const double bm = li0 * f3[SRK_WF_BP] + li1 * f3[SRK_WF_BP + 1] + li2 * f3[SRK_WF_BP + 2];
+                    double z[10];
+                    z[0] = am * f3[SRK_WF_AF0];
+                    z[1] = bm * f3[SRK_WF_BF1];
+                    z[2] = am * f3[SRK_WF_G];
+                    z[3] = bm * f3[SRK_WF_G];
+#pragma unroll
+                    for (int i = 4; i < 10; ++i) z[i] = am * f3[SRK_WF_AF4 + i - 4] + bm * f3[SRK_WF_BF4 + i - 4];
+                    double2* wp = reinterpret_cast<double2*>(bw + dst3); // (3 pl + m) LDW + 10 a: 16-byte aligned
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) racc3[i] = fma(z[i], hm, racc3[i]);
+                }
+            } else {
             if (q2 < nq2) {
                 const double2* E2 = reinterpret_cast<const double2*>(sE[pb + pl2]);
                 const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
-                const double i0 = e01.x, l10 = e01.y, i1 = e23.x, l20 = e23.y, l21 = e45.x, i2 = e45.y;
-                if constexpr (WStore<WT>::factored) {
-                    // Z = L^-1 (Ap Af + Bp Bf) = (L^-1 Ap) Af + (L^-1 Bp) Bf: the substitution once per observation, then two
-                    // multiply-adds an entry
-                    const double a0 = fap[0] * i0, a1 = (fap[1] - l10 * a0) * i1, a2 = (fap[2] - l20 * a0 - l21 * a1) * i2;
-                    const double b0 = fbp[0] * i0, b1 = (fbp[1] - l10 * b0) * i1, b2 = (fbp[2] - l20 * b0 - l21 * b1) * i2;
-                    const double ah = a0 * e67.x + a1 * e67.y + a2 * e89.x, bh = b0 * e67.x + b1 * e67.y + b2 * e89.x;
-#pragma unroll
-                    for (int b = 0; b < NBT; ++b) {
-                        const int i = i02 + 3 * b;
-                        if (i < 10) {
-                            const double af = pre2[b][0], bf = pre2[b][1];
-                            double* wp = bw + dst2 + i;
-                            wp[0] = a0 * af + b0 * bf; wp[LDW] = a1 * af + b1 * bf; wp[2 * LDW] = a2 * af + b2 * bf;
-                            racc2[b] += ah * af + bh * bf;
-                        }
-                    }
-                } else {
+                const double I00 = e01.x, I10 = e01.y, I11 = e23.x, I20 = e23.y, I21 = e45.x, I22 = e45.y;
 #pragma unroll
                 for (int b = 0; b < NBT; ++b) {
                     const int i = i02 + 3 * b;
                     if (i < 10) {
-                        const double z0 = pre2[b][0] * i0;
-                        const double z1 = (pre2[b][1] - l10 * z0) * i1;
-                        const double z2 = (pre2[b][2] - l20 * z0 - l21 * z1) * i2;
+                        const double z0 = I00 * pre2[b][0];
+                        const double z1 = I10 * pre2[b][0] + I11 * pre2[b][1];
+                        const double z2 = I20 * pre2[b][0] + I21 * pre2[b][1] + I22 * pre2[b][2];
                         double* wp = bw + dst2 + i;
                         wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
                         racc2[b] += z0 * e67.x + z1 * e67.y + z2 * e89.x;
                     }
                 }
-                }
+            }
             }
             // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
             if (nb < PB)
@@ -1949,9 +1965,16 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 lds_barrier(); // the products of rounds r, r + 1; Z of rounds r + 2, r + 3 are visible
                 MM_ACC(64 * SRK_MM_CW, 12, tacc);
             }
+            if constexpr (WStore<WT>::factored) {
+                if (sm3 < 3 && pl3 < PB) {
 #pragma unroll
-            for (int b = 0; b < NBT; ++b)
-                if (i02 < 3 && i02 + 3 * b < 10 && a2 < nf && pl2 < PB) atomicAdd(&sRhs[10 * a2 + i02 + 3 * b], racc2[b]);
+                    for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a3 + i], racc3[i]);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < NBT; ++b)
+                    if (i02 < 3 && i02 + 3 * b < 10 && a2 < nf && pl2 < PB) atomicAdd(&sRhs[10 * a2 + i02 + 3 * b], racc2[b]);
+            }
         } else
         for (int r = 0; r < R; ++r) {
             if (r + 2 < R) stage_round(sBuf + wi * WB);

@@ -26,6 +26,7 @@
 // advance in lock step through one launch sequence, and the separator system is chunked again.  A plain solve is a
 // batch of one.  The solver has no atomics and a fixed summation order (bit-reproducible).
 #include "srk_dev.hpp"
+#include <cstdlib>
 
 #define NB 64
 #define NBO SRK_CHOL_NB      // 256, outer panel
@@ -97,9 +98,10 @@ __device__ __forceinline__ double fast_rsqrt(double d)
 // DEFERRED behind the barrier and issued among the dependent instructions of the next group's 4 x 4 factorisation (independent
 // work for that latency-bound chain); the finals Y are double-buffered for it.  Every entry still receives the groups'
 // updates in the same order with the same operands: results are bit-identical to the former order.
-// The reciprocals of the 4 x 4 factor take ONE Newton step on the v_rcp_f64 seed (tools/ubench/rcp_acc.hip: relative error
-// after one step <= 2 ulp): they only scale multipliers, a relative error of 1e-16 there is one more rounding of an entry of L;
-// everything a hand-off partner recomputes (1 / L_tt of the stored factor) keeps the two-step reciprocal.
+// The reciprocals of the 4 x 4 factor take ONE Newton step on the v_rcp_f64 seed (tools/ubench/rcp_acc.hip on gfx950: seed
+// 4.6e-8, one step 2.1e-15, two steps 1.1e-16 relative): they only scale the multipliers of a rank-1 term, i.e. act as a
+// relative perturbation 2e-15 of that term -- an order of magnitude below the n eps |L| |L^T| rounding bound of a 256-column
+// block; everything a hand-off partner recomputes (1 / L_tt of the stored factor) keeps the two-step reciprocal.
 __device__ __forceinline__ double fast_rcp1(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
@@ -1281,7 +1283,8 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
         if (fused) {
             ++sync->epoch;
             if (sync->epoch == 0) ++sync->epoch; // the flag words start at 0
-            LAUNCH(k_step256, dim3((unsigned)(5 + row_wgs), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, K, sync->flags,
+            static const unsigned pad_lds = getenv("SRK_STEP_PAD_LDS") ? 8192u : 0u; // development: one workgroup per CU again
+            LAUNCH(k_step256, dim3((unsigned)(5 + row_wgs), 1, (unsigned)n), dim3(256), pad_lds, s, B, st, r2b, r2e, K, sync->flags,
                    sync->epoch, d_info);
         }
         for (int jsub = 0; jsub < NBO / NB && !fused; ++jsub) {
