@@ -1951,6 +1951,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             // r + 1 are multiplied while the helpers stage r + 2 (loads issued half a double round ago) and r + 3 (loads
             // issued at the start of this one); round u lives in buffer u % 6.
             for (int r = 0; r < R; r += 2) {
+#ifdef SRK_MM_NOHELP // ablation only (wrong results): the helpers stage nothing after the prologue -- what the MFMA streams take alone
+                if (d.N >= 0) { lds_barrier(); continue; }
+#endif
                 if (r + 2 < R) stage_round2(r + 2, sBuf + ((r + 2) % 6) * WB);
 #ifdef SRK_MM_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
