@@ -1522,9 +1522,27 @@ int srk_ba_phase_solve(srk_ba* h)
     rc = read_info(h, &info);
     if (rc != SRK_OK) return rc;
     if (info && srk_debug()) fprintf(stderr, "srk_ba_phase_solve: info=%d (1 = pivot, 4 = non-finite solution, 8 = hand-off timeout of the fused solve)\n", info);
-    if (info & 8) {
+    if ((info & 8) && h->A->plan.P >= 2) {
+        // a hand-off of the fused outer step timed out: a scheduling event, not a numerical failure.  The chunked solve works
+        // on copies (the system itself is intact): the plan's buffers back to zero, fusion off for good, once more unfused.
         ++h->sync_timeouts;
-        h->last_error = "a hand-off of the fused solve timed out (srk_ba_set_solver_fusion(h, 0) selects the unfused launch sequence)";
+        h->chol_fused = false;
+        for (auto& a : h->att) a.sync.fused = false;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < h->A->plan_bufs.size(); ++i)
+            if (h->A->plan_zeroed[i]) HIPCHK(h, hipMemsetAsync(h->A->plan_bufs[i].p, 0, h->A->plan_bufs[i].bytes, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->A->info.p, 0, 4, h->stream));
+        rc = phase_solve(h, false);
+        if (rc != SRK_OK) return rc;
+        rc = read_info(h, &info);
+        if (rc != SRK_OK) return rc;
+    } else if (info & 8) {
+        // (the single-chain / dense solve factorises the system in place: nothing to repeat from; the caller builds it again)
+        ++h->sync_timeouts;
+        h->chol_fused = false;
+        for (auto& a : h->att) a.sync.fused = false;
+        h->last_error = "a hand-off of the fused solve timed out; the system was factorised in place: call srk_ba_phase_schur again "
+                        "(the unfused launch sequence is selected from now on)";
     }
     if (info) h->poisoned = true;
     return info ? 1 : 0;
@@ -2415,9 +2433,24 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     HIPCHK(h, hipEventRecord(h->ev[15], s));
     HIPCHK(h, hipGetLastError());
     int info = 0;
-    HIPCHK(h, hipMemcpyAsync(bp.data(), dx.p, bp.size() * 8, hipMemcpyDeviceToHost, s));
+    std::vector<double> xs(bp.size());
+    HIPCHK(h, hipMemcpyAsync(xs.data(), dx.p, xs.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(&info, dinfo.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (info & 8) { // a hand-off timed out (a scheduling event): the inputs again from the host copies, unfused, once
+        ++h->sync_timeouts;
+        sync.fused = false;
+        HIPCHK(h, hipMemcpyAsync(dA.p, Ap.data(), Ap.size() * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(dw.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemsetAsync(dinfo.p, 0, 4, s));
+        srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr, nullptr,
+                       P<double>(ddinv), nullptr, &sync);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(xs.data(), dx.p, xs.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(&info, dinfo.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    bp.swap(xs);
     if (ms_factor) {
         float ms = 0;
         hipEventElapsedTime(&ms, h->ev[14], h->ev[15]);

@@ -734,10 +734,17 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
             SST(2 + 6 * d);
             if (bad && tid == 0) atomicOr(info, 1);
             publish_tile(sD, A + r0 * ld + k0 + d * NB);
-            if (d == 0 && z == 0 && g_step_fault > 0) { // (test hook: a lost hand-off)
+            if (d == 0 && z == 0) { // (test hook: a lost hand-off.  ONE lane reads the flag -- with two attempt slots in flight
+                // another launch may change it between two lanes' reads -- and the branch is workgroup-uniform)
+                if (tid == 0) {
+                    const int f = g_step_fault;
+                    if (f > 0) atomicSub(&g_step_fault, 1);
+                    sDiag[0] = f > 0 ? 1.0 : 0.0; // (sDiag is free here: potrf64 is done with it)
+                }
                 __syncthreads();
-                if (tid == 0) atomicSub(&g_step_fault, 1);
-                return;
+                const bool fault = sDiag[0] != 0.0;
+                __syncthreads();
+                if (fault) return;
             }
             st_publish(fl + ST_F(d), epoch);
             SST(3 + 6 * d);

@@ -1185,6 +1185,40 @@ def test_a_lost_hand_off_times_out_and_the_attempt_is_repeated_with_the_panel_se
         gpu.set_solver_fusion(1)
 
 
+def test_a_lost_hand_off_in_the_staged_solve_calls_is_repeated_unfused(gpu):
+    """The same scheduling event through the step-wise entry points: srk_ba_phase_solve (nested plan: the system is intact,
+    the solve runs again with the panel sequence and reports success) and srk_ba_dense_spd_solve (inputs staged again from
+    the host copies) -- a hand-off timeout is not reported as a numerical failure."""
+    spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
+    sc = sa.generate_scene(spec)
+    try:
+        gpu.set_solver_fusion(1)
+        assert gpu.upload(spec.f0, sc) and gpu.rcs_chunks() >= 2
+        gpu.phase_error()
+        gpu.phase_derivatives()
+        gpu.phase_schur(1e-3)
+        assert gpu.phase_solve()
+        ref = gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:].copy()
+        gpu.phase_schur(1e-3)
+        before = gpu.solver_sync_timeouts()
+        sa.lib().srk_dbg_step_fault(1)
+        assert gpu.phase_solve()                      # timed out inside, repeated unfused, succeeded
+        assert gpu.solver_sync_timeouts() == before + 1
+        assert np.array_equal(gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:], ref)   # fused and unfused sequences agree bit for bit
+        gpu.set_solver_fusion(1)
+        rng = np.random.RandomState(5)
+        A = rng.randn(300, 300)
+        A = A @ A.T + 300 * np.eye(300)
+        b = rng.randn(300)
+        sa.lib().srk_dbg_step_fault(1)
+        ok, x, _ = gpu.dense_spd_solve(A, b)
+        assert ok and np.abs(x - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
+        assert gpu.solver_sync_timeouts() == before + 2
+    finally:
+        sa.lib().srk_dbg_step_fault(0)
+        gpu.set_solver_fusion(1)
+
+
 def test_chunked_end_to_end_matches_single_chain(gpu):
     spec = sa.SceneSpec(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2)
     sc = sa.generate_scene(spec)
