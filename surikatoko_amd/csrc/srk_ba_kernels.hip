@@ -1571,10 +1571,11 @@ __device__ const signed char srk_mm_tiles13[SRK_MM_CW][SRK_MM_SLOTS][2] = {
     { { 12, 8 }, { 12, 9 }, { 12, 10 }, { 12, 11 }, { 12, 12 }, { 8, 8 }, { 9, 8 }, { 9, 9 } },
     { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { -1, 0 }, { -1, 0 } },
 };
-// RAGGED: the instantiation for runs over the UNION of different frame lists (W + Y form, masks); the other one takes the
-// uniform runs (SYRK form, double rounds).  Two kernels, two register allocations: a workgroup whose run is of the other kind
-// leaves at once, and the host launches an instantiation only when the scene has runs of its kind.
-template <typename WT, bool RAGGED>
+// KIND 0: every run of the scene is uniform (all its landmarks see the same frames: the bench scenes) -- SYRK form, double
+// rounds; KIND 1: the scene has runs over the UNION of different frame lists -- W + Y form with masks, which serves a uniform
+// run as well (full masks), so a scene with both kinds (the dino stand-in) is ONE launch, not two latency-bound ones.  Two
+// instantiations, two register allocations (together: 30 spilled registers); the host picks by what the scene holds.
+template <typename WT, int KIND>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
@@ -1616,9 +1617,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
     const int nfu = grp_nf[blockIdx.x];
-    constexpr bool ragged = RAGGED;
-    if ((nfu < 0) != RAGGED) return;
-    const int nf = ragged ? -nfu : nfu;
+    constexpr bool ragged = KIND == 1;
+    if (KIND == 0 && nfu < 0) return; // (never launched on such a scene)
+    const int nf = nfu < 0 ? -nfu : nfu;
     if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
     if (tid < nf * 10) {
         sRhs[tid] = 0.0;
@@ -1714,6 +1715,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         static_assert(3 * QMAX <= NH, "staging lanes");
         const int sm = h / QMAX, sq = h - sm * QMAX;
         double pre[10];
+        double fpre[2 + SRK_WF_PLANES - SRK_WF_AF0]; // (fp64 storage) Ap[sm], Bp[sm], then planes SRK_WF_AF0 .. of the observation
         int sdst, nq_pre = 0;
         {
             const int pl = sq / nf, a = sq - pl * nf; // uniform runs: landmark q / nf, slot q % nf
@@ -1723,16 +1725,40 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
             nq_pre = sm < 3 ? rb - ra : 0;
             if (sq < nq_pre) {
+                if constexpr (WStore<WT>::factored) {
+                    // fp64 storage: the raw factors stay in flight -- the lane's two point-side factors (plane offset sm Os in
+                    // the lane part of the address, wave-uniform plane bases) and the 15 frame-side ones
+                    const unsigned voff = (unsigned)(o0 + ra + sq), vrow = voff + (unsigned)sm * (unsigned)d.Os;
+                    fpre[0] = (W + (int64_t)SRK_WF_AP * d.Os)[vrow];
+                    fpre[1] = (W + (int64_t)SRK_WF_BP * d.Os)[vrow];
 #pragma unroll
-                for (int i = 0; i < 10; ++i) pre[i] = w_entry<WT>(W, d.Os, o0 + ra + sq, 10 * sm + i);
+                    for (int k = SRK_WF_AF0; k < SRK_WF_PLANES; ++k) fpre[2 + k - SRK_WF_AF0] = (W + (int64_t)k * d.Os)[voff];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) pre[i] = w_entry<WT>(W, d.Os, o0 + ra + sq, 10 * sm + i);
+                }
                 if (ragged)
                     sdst = (3 * (obs_pt[o0 + ra + sq] - (int)(p0 + r * PB)) + sm) * LDW + 10 * (int)obs_slot[o0 + ra + sq];
             }
         };
         auto stage_round = [&](double* bw) { // `pre` -> W in LDS
             if (sq < nq_pre) {
+                if constexpr (WStore<WT>::factored) {
+                    const double ap = fpre[0], bp = fpre[1], gq = fpre[2 + SRK_WF_G - SRK_WF_AF0];
+                    double w[10];
+                    w[0] = ap * fpre[2];
+                    w[1] = bp * fpre[2 + SRK_WF_BF1 - SRK_WF_AF0];
+                    w[2] = ap * gq;
+                    w[3] = bp * gq;
 #pragma unroll
-                for (int i = 0; i < 10; ++i) bw[sdst + i] = pre[i];
+                    for (int i = 4; i < 10; ++i)
+                        w[i] = ap * fpre[2 + SRK_WF_AF4 - SRK_WF_AF0 + i - 4] + bp * fpre[2 + SRK_WF_BF4 - SRK_WF_AF0 + i - 4];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) bw[sdst + i] = w[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) bw[sdst + i] = pre[i];
+                }
             }
         };
         // Y = E^-1 W: helper wave ypl forms the rows of staged landmark ypl, its lanes take the columns lane + 64 i, and
@@ -2369,14 +2395,14 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
     if (!no_ws && n_wide + n_mid < n_groups) { // runs over at most SRK_WS_NF frames: the MFMA kernel
         if (env_valu) SRK_SCHUR_LAUNCH(k_schur_ws, block, double, );
         else {
-            if (n_mm_uniform > 0) {
-                if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, false>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);
-                else hipLaunchKernelGGL((k_schur_mm<double, false>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);
-            }
-            if (n_mm_ragged > 0) {
-                if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, true>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);
-                else hipLaunchKernelGGL((k_schur_mm<double, true>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);
-            }
+#define SRK_MM_LAUNCH(KIND)                                                                                                      \
+    do {                                                                                                                         \
+        if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, KIND>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);   \
+        else hipLaunchKernelGGL((k_schur_mm<double, KIND>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);           \
+    } while (0)
+            if (n_mm_ragged > 0) SRK_MM_LAUNCH(1);
+            else if (n_mm_uniform > 0) SRK_MM_LAUNCH(0);
+#undef SRK_MM_LAUNCH
         }
     }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread

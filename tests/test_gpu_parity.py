@@ -1199,7 +1199,8 @@ def test_a_lost_hand_off_in_the_staged_solve_calls_is_repeated_unfused(gpu):
         gpu.phase_schur(1e-3)
         assert gpu.phase_solve()
         ref = gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:].copy()
-        gpu.phase_schur(1e-3)
+        # (the nested solve works on copies: the SAME system again -- a second Schur sum would differ in the last bits, its
+        # fp64 atomics arrive in another order)
         before = gpu.solver_sync_timeouts()
         sa.lib().srk_dbg_step_fault(1)
         assert gpu.phase_solve()                      # timed out inside, repeated unfused, succeeded
