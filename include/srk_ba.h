@@ -92,24 +92,30 @@ int srk_ba_set_stream(srk_ba*, void* hip_stream);
 
 /* ---- multi-GPU (landmark sharding) ----
  * Every rank owns a contiguous pnt_ind range and passes only that range to the scene calls; cameras
- * are replicated.  Two exchange steps per LM attempt call `fn` to sum `count` doubles in place across
- * ranks: the packed skyline of the assembled reduced camera system with its rhs behind it (the frame
- * blocks are added before the exchange, so they need none of their own), and {error, solver status,
- * point-update status}; plus one at the start of an optimise call (initial error, observation count).
+ * are replicated.  With world_size >= 2 an LM iteration runs in ROUNDS of the next two or three damping
+ * factors: every rank builds each factor's reduced camera system on its landmarks (the
+ * frame blocks are added before the exchange, so they need none of their own), the packed band of
+ * factor k with its rhs behind it is reduced to rank k, rank k solves and broadcasts the frame
+ * corrections, every rank back-substitutes and scores every factor on its shard, and one all-reduce
+ * carries the {error, solver status, point-update status} words of all factors; plus one exchange at
+ * the start of an optimise call (initial error, observation count).  (SRK_MULTI_SCHEDULE=allreduce in
+ * the environment of srk_ba_create: the older schedule -- the band all-reduced, every rank solves.)
+ * The callback `fn` sums `count` doubles in place across ranks; it is all the library needs (a reduce
+ * is a sum the other ranks ignore, a broadcast a sum of a buffer they zeroed).
  * Buffers downloaded with srk_ba_download (GRAD, UG, ...) hold this rank's partial sums.
- * `dev_ptr` is device memory on the handle's stream; the hook must return after the reduction is
- * ordered on that stream (or complete).  Returns 0 on success. */
+ * `dev_ptr` is device memory; the hook is called with everything queued for the buffer complete and
+ * must return after the reduction is complete.  Returns 0 on success. */
 typedef int (*srk_allreduce_fn)(void* ctx, double* dev_ptr, int64_t count);
 int srk_ba_set_allreduce(srk_ba*, srk_allreduce_fn fn, void* ctx, int rank, int world_size);
-/* The same exchanges natively: RCCL all-reduces (sum, fp64) enqueued on the stream of the LM attempt that needs them,
- * with no host synchronisation and no Python -- what a C++ caller on the 8 GPUs of a node uses (one process or thread
- * per GPU, one handle each).  librccl.so is opened on first use.
+/* The same exchanges natively: ncclReduce / ncclBroadcast groups and ncclAllReduce (sum, fp64) on a stream of the handle,
+ * ordered against the attempts' streams by events, with no host synchronisation and no Python -- what a C++ caller on the
+ * 8 GPUs of a node uses (one process or thread per GPU, one handle each).  librccl.so is opened on first use.
  *   srk_ba_rccl_get_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by any means;
  *   srk_ba_rccl_init:          every rank creates the communicator on its handle's device (collective call);
  *   srk_ba_rccl_init_second:   (optional, collective, after srk_ba_rccl_init, with a second unique id) a communicator of
- *                              its own for the second attempt slot: with it the LM loop keeps its speculative attempt
- *                              pairs with several ranks (each slot's all-reduces on its own stream and communicator);
- *                              without it one attempt runs at a time;
+ *                              its own for the second attempt slot of the `allreduce` schedule (speculative attempt pairs
+ *                              with several ranks, each slot's all-reduces on its own stream and communicator); the
+ *                              default schedule needs one communicator only;
  *   srk_ba_rccl_set_comm:      use a communicator (ncclComm_t) the caller owns instead; NULL detaches.
  * Either replaces a callback set with srk_ba_set_allreduce.  Call before srk_ba_upload_scene. */
 int srk_ba_rccl_get_unique_id(void* id128 /* out: 128 bytes */);
