@@ -88,9 +88,11 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               int32_t* irr /* [0] count + list of landmarks k_schur_mm hands back to the inverse path */,
                               int64_t n_mm_uniform, int64_t n_mm_ragged /* runs of <= SRK_WS_NF_HOST frames by kind */);
 // tracks longer than SRK_GRP_MAXNF_HOST frames: runs of <= SRK_LONG_PTS_HOST landmarks over a frame set of
-// <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur
+// <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur.
+// (Round 3: 4096 -- the limit is only the row length of the run_frames table; it was 256, and a track over more frames fell
+// back to the per-landmark global-atomics kernel, a 30x cliff on all-visible scenes of more than 256 frames.)
 #define SRK_LONG_PTS_HOST 128
-#define SRK_LONG_MAXNF_HOST 256
+#define SRK_LONG_MAXNF_HOST 4096
 #define SRK_LONG_FB_HOST 8
 void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const double* W, const double* Vg, double* S, double* rhs,
                            const int32_t* item /* [n_items][4]: run, row block, column block (<= row block), 0 */,

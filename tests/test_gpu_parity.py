@@ -210,6 +210,41 @@ def test_phases_on_synthetic_scenes(orc, gpu, name, c):
     _check(out, sc.M, corr_tol=1e-7)
 
 
+def test_tracks_over_more_than_256_frames_take_the_mfma_long_track_kernel(orc, gpu):
+    """An all-visible scene of 270 frames (every track in every frame, as the reference's demos build their scenes): tracks
+    over more than 256 frames used to fall back to the per-landmark global-atomics kernel; k_schur_long now takes any frame
+    set.  Blocks, reduced camera system (2693^2) and right-hand side against the oracle (its QR of that system is skipped: the
+    Schur sum is what is under test), then the GPU's own step must decrease the error."""
+    spec = sa.SceneSpec(n_frames=270, grid_nx=8, grid_ny=6, vis_window=0)
+    sc = sa.generate_scene(spec)
+    so = _orc_scene(orc, sc)
+    ok, _ = orc.normalize(so)
+    assert ok and gpu.upload(spec.f0, sc)
+    e0, _ = gpu.phase_error()
+    eo, _ = orc.reproj_error(spec.f0, so)
+    assert e0 == pytest.approx(eo, rel=1e-12)
+    gradE, V, U, W = orc.derivatives(spec.f0, so)
+    gpu.phase_derivatives()
+    dU = _check_blocks_by_class(gpu.buffer(B.BUF_POINT_BLOCKS).reshape(-1, 3, 3), V, gpu.buffer(B.BUF_FRAME_BLOCKS).reshape(-1, 10, 10), U,
+                                gpu.buffer(B.BUF_POINT_FRAME).reshape(-1, 3, 10), W, gpu.buffer(B.BUF_GRAD), gradE, eo)
+    orc.set_skip_solve(True)
+    try:
+        _, _, S, rhs = orc.two_phase(so, gradE, V, U, W, 1e-3, want_system=True)
+    finally:
+        orc.set_skip_solve(False)
+    gpu.phase_schur(1e-3)
+    keep = _reduced_index(sc.M) >= 0
+    Sg = gpu.buffer(B.BUF_RCS).reshape(10 * sc.M, 10 * sc.M)[np.ix_(keep, keep)]
+    rg = gpu.buffer(B.BUF_RCS_RHS)[keep]
+    assert rel_err(Sg, S) < 1e-10 and rel_err(rg, rhs) < 1e-10
+    _check_system_by_class(Sg, S, rg, rhs, dU[keep], eo)
+    assert gpu.phase_solve()
+    gpu.phase_backsub(1e-3)
+    gpu.phase_accept()
+    e1, _ = gpu.phase_error()
+    assert e1 < e0
+
+
 # ------------------------------------------------------------------ the run-based derivative kernel (k_jac_runs)
 
 JAC_RUN_SCENES = {
