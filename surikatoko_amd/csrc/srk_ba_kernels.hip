@@ -1555,10 +1555,16 @@ __device__ __forceinline__ void schur_mm_steps_blk(srk_double4 (&acc)[SRK_MM_SLO
         for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi, o.b[j], acc[4 + j], 0, 0, 0);
     };
     Ops o0, o1;
+#ifdef SRK_MM_FEWREADS // ablation only (wrong results): one operand set serves the three K steps -- what the reads cost the stream
+    load(o0, 0);
+    mac(o0); mac(o0); mac(o0);
+    (void)o1;
+#else
     load(o0, 0);
     load(o1, 1); mac(o0);
     load(o0, 2); mac(o1);
     mac(o0);
+#endif
 }
 // nt = 13 (20 frames): the 91 tiles of the lower triangle over the 12 multiplying waves.  Nine waves take a 2 x 4 block
 // (two tile rows, four tile columns; where the block reaches over the diagonal that tile is computed and not flushed),
