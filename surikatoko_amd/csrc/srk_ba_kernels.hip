@@ -1593,10 +1593,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     constexpr int KR = 3 * PB;                 // k rows of a round
     constexpr int LDW = SRK_MM_LDW;            // row stride (doubles)
     constexpr int WB = KR * LDW;               // one buffer: W or Y of a round
-    constexpr int CAP = 6 * WB;                // W0 | W1 | W2 | Y0 | Y1 | Y2 (ragged runs use Y0, Y1); the flush uses all of it
+    constexpr int CAP = 6 * WB;                // KIND 1: W0 | W1 | W2 | Y0 | Y1; KIND 0: six rounds of Z (round u in buffer u % 6)
     constexpr int QMAX = PB * SRK_WS_NF;       // observations of a round
     constexpr int NH = SRK_MM_THREADS - 64 * SRK_MM_CW; // helper lanes
-    constexpr int NW = SRK_MM_THREADS / 64;
     static_assert(SRK_WS_NF * 10 <= LDW && KR % 4 == 0, "round buffers");
     static_assert(SRK_MM_CW * SRK_MM_SLOTS >= 13 * 14 / 2, "tiles do not fit the multiplying waves");
     static_assert((SRK_GRP_MAXPTS + PB - 1) / PB < 64, "a run's row_ptr entries do not fit a wave");
@@ -1685,28 +1684,6 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         for (int j = 0; j < NI; ++j)
             if (dst[j] >= 0) sBuf[dst[j]] = v[j];
     }
-    // flush: TR tile rows (16 TR rows of the sum, LDW columns) at a time go through the arena as a dense block, then
-    // leave as one wave per row of S, the lanes walking the row's 10 (a + 1) columns of the lower block triangle
-    constexpr int TR = CAP / (16 * LDW);
-    auto flush_stream = [&](int t0) { // rows 16 t0 .. 16 (t0 + TR) - 1
-        for (int rho = wv; rho < 16 * TR; rho += NW) {
-            const int Rr = 16 * t0 + rho;
-            if (Rr >= nf10) break;
-            const int row = sVar[Rr];
-            if (row < 0) continue;
-            const double* src = sBuf + rho * LDW;
-            double* dst = S + (int64_t)row * d.ld;
-            const int w = 10 * (Rr / 10 + 1);
-            for (int cw = lane; cw < w; cw += 64) {
-                const int col = sVar[cw];
-                if (col < 0) continue;
-#ifdef SRK_SCH_NOFLUSH
-                if (d.N >= 0) continue;
-#endif
-                atomicAdd(&dst[col], -src[cw]);
-            }
-        }
-    };
     const int nt = (nf10 + 15) >> 4; // tile rows of the sum
     __syncthreads(); // sE, sVar, sRhs and W of rounds 0 and 1 are visible
     MM_STAMP(1);
@@ -2039,11 +2016,6 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #pragma unroll
         for (int i = 0; i < NC; ++i)
             if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
-        for (int t0 = 0; t0 < nt; t0 += TR) {
-            lds_barrier();
-            lds_barrier();
-            flush_stream(t0);
-        }
     } else {
         // ---- multipliers: wave wv owns tiles u = wv + SRK_MM_CW s (row-major over (ti, tj <= ti)) of the nt x nt grid
         const int n_tiles = nt * (nt + 1) / 2;
@@ -2172,33 +2144,33 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #undef SRK_MM_CASE
         }
         MM_STAMP(3);
-        // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg.  A tile just below the
-        // diagonal also supplies the mirror images the diagonal blocks it cuts need above the tile diagonal.
-#pragma nounroll
-        for (int t0 = 0; t0 < nt; t0 += TR) {
-            lds_barrier();
+        // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg.
+        // (Round 3) Straight from the accumulator registers: every lane adds its entries on and below the diagonal of the
+        // sum (row >= column: S is lower-triangle authoritative; the parts of the diagonal 10 x 10 blocks above it, which the
+        // LDS flush also wrote, are never read).  The LDS flush -- three or four passes of tile rows through the arena, two
+        // barriers each, then one wave per row of S -- took 12.8 us of a workgroup's 98; its atomics themselves cost nothing
+        // since the staggered start (SRK_SCH_NOFLUSH: 429.5 against 430 us), so what it spent was the shuffling.  A wave's
+        // atomic instruction covers 16 consecutive columns of four rows of S.  Schur phase 432-435 -> 425 us.
 #pragma unroll
-            for (int s = 0; s < SRK_MM_SLOTS; ++s) {
-                if (!((onmask >> s) & 1u)) continue;
-                const int ti = ta[s] >> 4, tj = tb[s] >> 4; // wave-uniform
-                if (ti >= t0 && ti < t0 + TR) {
+        for (int s = 0; s < SRK_MM_SLOTS; ++s) {
+            if (!((onmask >> s) & 1u)) continue;
+            const int Cc = tb[s] + lr;
+            const int colv = Cc < nf10 ? sVar[Cc] : -1;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) sBuf[(ta[s] - 16 * t0 + lk + 4 * reg) * LDW + tb[s] + lr] = acc[s][reg];
-                }
-                if (ti == tj + 1 && tj >= t0 && tj < t0 + TR) {
-                    const int Cc = tb[s] + lr, aC = Cc / 10;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int Rr = ta[s] + lk + 4 * reg;
-                        if (Rr < 10 * (aC + 1)) sBuf[(Cc - 16 * t0) * LDW + Rr] = acc[s][reg]; // same diagonal block
-                    }
-                }
+            for (int reg = 0; reg < 4; ++reg) {
+                const int Rr = ta[s] + lk + 4 * reg;
+                if (colv < 0 || Rr >= nf10 || Cc > Rr) continue;
+                const int rowv = sVar[Rr];
+                if (rowv < 0) continue;
+#ifdef SRK_SCH_NOFLUSH
+                if (d.N >= 0) continue;
+#endif
+                atomicAdd(&S[(int64_t)rowv * d.ld + colv], -acc[s][reg]);
             }
-            lds_barrier();
-            flush_stream(t0);
         }
     }
-    // rhs += sum F^T E^-1 g (the helpers' sRhs adds precede the flush's barriers; nf >= 1 means at least one pass)
+    lds_barrier(); // the helpers' sRhs adds are complete
+    // rhs += sum F^T E^-1 g (the helpers' sRhs adds precede a barrier every wave passes)
     if (tid < nf10 && sVar[tid] >= 0) atomicAdd(&rhs[sVar[tid]], sRhs[tid]);
     MM_STAMP(4);
 #ifdef SRK_MM_STAMPS
