@@ -1636,7 +1636,55 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int64_t o0 = row_ptr[p0];
     // LDS column of observation (staged landmark pl, frame slot a), W row k = 10 m + r:  (3 pl + m) LDW + 10 a + r
     // rounds 0 and 1 are staged by the whole workgroup, their loads in flight together with the 3x3 blocks' below
-    {
+    constexpr bool rows01 = KIND == 0 && WStore<WT>::factored; // rounds 0 and 1 staged as Z rows here (below)
+    if constexpr (rows01) {
+        // fp64 factors, uniform runs: thread (rd, sm, sq) of the first 2 * 3 * QMAX takes row sm of observation sq of round
+        // rd, like the helpers' stage_round2 -- its 21 factor loads are in flight together with the 3x3 blocks' loads, Z leaves
+        // after ONE barrier (the raw-W pass and the helpers' in-place L^-1 pass that this replaces cost a workgroup ~9.7 us
+        // before its first MFMA; this ~4)
+        static_assert(2 * 3 * QMAX <= SRK_MM_THREADS, "prologue row threads");
+        const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
+        const int rd = tid / (3 * QMAX), rem = tid - rd * (3 * QMAX);
+        const int sm = rem / QMAX, sq = rem - sm * QMAX;
+        const int oa = rd ? o1 : 0, nq = rd < 2 ? (rd ? o2 - o1 : o1) : 0;
+        const bool row_on = sq < nq;
+        double f[SRK_WF_PLANES];
+        if (row_on) {
+            const unsigned voff = (unsigned)(o0 + oa + sq);
+#pragma unroll
+            for (int k = 0; k < SRK_WF_PLANES; ++k) f[k] = (W + (int64_t)k * d.Os)[voff];
+        }
+        if (tid < np) {
+            double Lc[6], hh[3];
+            const int st = point_block_cholesky(Vg, d.Ns, p0 + tid, c, Lc, hh);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sE[tid][k] = st == 1 ? Lc[k] : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) sE[tid][6 + m] = st == 1 ? hh[m] : 0.0;
+            if (st == 2) irr[1 + atomicAdd(&irr[0], 1)] = (int32_t)(p0 + tid);
+        }
+        __syncthreads(); // sE; sRhs is zeroed
+        if (row_on) {
+            const int pl = sq / nf, a = sq - pl * nf;
+            const double* E = sE[rd * PB + pl];
+            const int r3 = sm * (sm + 1) / 2;
+            const double li0 = E[r3], li1 = sm >= 1 ? E[r3 + 1] : 0.0, li2 = sm >= 2 ? E[r3 + 2] : 0.0, hm = E[6 + sm];
+            const double am = li0 * f[SRK_WF_AP] + li1 * f[SRK_WF_AP + 1] + li2 * f[SRK_WF_AP + 2];
+            const double bm = li0 * f[SRK_WF_BP] + li1 * f[SRK_WF_BP + 1] + li2 * f[SRK_WF_BP + 2];
+            double z[10];
+            z[0] = am * f[SRK_WF_AF0];
+            z[1] = bm * f[SRK_WF_BF1];
+            z[2] = am * f[SRK_WF_G];
+            z[3] = bm * f[SRK_WF_G];
+#pragma unroll
+            for (int i = 4; i < 10; ++i) z[i] = am * f[SRK_WF_AF4 + i - 4] + bm * f[SRK_WF_BF4 + i - 4];
+            double2* wp = reinterpret_cast<double2*>(sBuf + rd * WB + (3 * pl + sm) * LDW + 10 * a);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], z[i] * hm);
+        }
+    } else {
         const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
         constexpr int NI = (2 * 30 * QMAX + SRK_MM_THREADS - 1) / SRK_MM_THREADS;
         double v[NI];
@@ -1939,11 +1987,17 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
         };
         load_mask(0);
+        auto zero_tail = [&](int r, double* bw) { // a short round: the k rows of the landmarks it does not have
+            const int nb = np - r * PB < PB ? np - r * PB : PB;
+            if (nb < PB)
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
+        };
         if (ragged) y_round(0, sBuf, sBuf + 3 * WB);
+        else if (rows01) zero_tail(0, sBuf);
         else z_round(0, sBuf);
         load_mask(1);
         if (!ragged) {
-            if (R > 1) z_round(1, sBuf + WB);
+            if (R > 1) { if (rows01) zero_tail(1, sBuf + WB); else z_round(1, sBuf + WB); }
 #pragma unroll
             for (int i = 0; i < NC; ++i) { // the two-pass rounds' share of the rhs: out of the registers before the loop
                 if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
