@@ -262,6 +262,20 @@ int64_t srk_ba_solver_sync_timeouts(srk_ba*);
  * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time. */
 int srk_ba_set_speculation(srk_ba*, int on);
 
+/* Internal frame order.  The reference's dense solve (bundle-adj-kanatani.cpp:1911) does not care how the frames are
+ * numbered; the skyline solver, its nested dissection and the derivative kernels' frame windows here want covisible frames
+ * to have nearby indices.  When the caller's numbering is far from banded (an unordered image set, a sequence that closes
+ * a loop) the frames are renumbered internally by reverse Cuthill-McKee on the covisibility graph; the gauge stays on the
+ * CALLER's frames 0 and 1, every download and the scene itself come back in the caller's order, results are those of the
+ * caller's order up to summation order.  One rank only (landmark shards keep the caller's order).
+ * mode -1 = automatic (default), 0 = never, 1 = whenever the ordering differs; takes effect at the next upload.
+ * srk_ba_frame_order: 1 = renumbered (to_internal[caller's frame] = internal index, may be NULL), 0 = caller's order.
+ * srk_frame_order: the decision and the numbering alone, on the host (no device needed). */
+int srk_ba_set_frame_reordering(srk_ba*, int mode);
+int srk_ba_frame_order(srk_ba*, int32_t* to_internal /* [M] or NULL */);
+int srk_frame_order(int mode, int64_t n_points, int32_t n_frames, const int64_t* obs_row_ptr, const int32_t* obs_frame,
+                    int32_t* to_internal /* [M] */);
+
 /* Derivative kernel selection (harness knob, the reference has one code path: bundle-adj-kanatani.cpp:1140-1448).
  * mode -1 = automatic: the run-based kernel (a lane keeps one frame's sums in registers over a run of landmarks with
  * identical frame lists) when the runs are long enough, else the per-observation kernels; 0 = per-observation kernels

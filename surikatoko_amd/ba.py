@@ -281,6 +281,18 @@ class BundleAdjustmentKanatani:
         """Run the next damping factor beside the current attempt (one rank, instrumentation off); next upload."""
         self._raise(self._lib.srk_ba_set_speculation(C.c_void_p(self._h), C.c_int(int(bool(on)))))
 
+    def set_frame_reordering(self, mode=-1):
+        """-1 automatic, 0 = keep the caller's frame order, 1 = renumber whenever the ordering differs (next upload)"""
+        self._raise(self._lib.srk_ba_set_frame_reordering(C.c_void_p(self._h), C.c_int(mode)))
+
+    def frame_order(self):
+        """None when the frames are stored in the caller's order, else to_internal[caller's frame]"""
+        to_int = np.zeros(self._scene.M if self._scene is not None else 0, np.int32)
+        rc = self._lib.srk_ba_frame_order(C.c_void_p(self._h), _p(to_int))
+        if rc < 0:
+            self._raise(rc)
+        return to_int if rc == 1 else None
+
     def set_solver_fusion(self, on=True):
         """Outer steps of the blocked Cholesky as one launch each (default) or as the panel / update launch sequence."""
         self._raise(self._lib.srk_ba_set_solver_fusion(C.c_void_p(self._h), C.c_int(int(bool(on)))))
@@ -434,7 +446,7 @@ class BundleAdjustmentKanatani:
         if rc == -1:
             raise ValueError("srk_ba: bad argument: " + msg)
         if rc == -3:
-            raise RuntimeError("srk_ba: no scene uploaded")
+            raise RuntimeError("srk_ba: not possible in this state (no scene uploaded?): " + msg)
         if rc == -4:
             raise MemoryError("srk_ba: out of device memory: " + msg)
         raise RuntimeError("srk_ba: device error: " + msg)

@@ -24,6 +24,7 @@
 #include <memory>
 #include <vector>
 #include <functional>
+#include <unordered_set>
 
 namespace {
 
@@ -56,6 +57,11 @@ struct srk_ba {
     DevBuf W, Vg, Ug, scratch;
     // landmarks are stored sorted by frame list (internal order); perm[internal] = caller's pnt_ind
     std::vector<int64_t> perm, row_ptr_user, row_ptr_int;
+    // Frames may be stored in another order than the caller's (frame_reorder below: unordered image sets, loop
+    // closures).  Both empty = the caller's order.  frame_int[caller's frame] = internal index, frame_user = its inverse;
+    // obs_rank[caller's observation] = its place inside its landmark's internal (re-sorted) observation list.
+    std::vector<int32_t> frame_int, frame_user, obs_rank;
+    int frame_order_mode = -1; // srk_ba_set_frame_reordering: -1 automatic, 0 never, 1 whenever the ordering differs from the caller's
     DevBuf grp_first, grp_count, grp_nf, grp_frames, obs_slot, pt_mask, gen_list, wg_jmin;
     // long tracks (more than SRK_GRP_MAXNF_HOST frames): runs over frame-block pairs, k_schur_long
     DevBuf lg_item, lg_np, lg_nf, lg_pts, lg_frames, lg_obs_off, lg_obs;
@@ -365,9 +371,18 @@ int srk_ba_set_stream(srk_ba* h, void* hip_stream)
     return SRK_OK;
 }
 
+// landmark shards must agree on the frame numbering: each rank's own renumbering (made from its shard at upload) would not
+static bool exchange_after_reordered_upload(srk_ba* h, int world_size)
+{
+    if (world_size < 2 || !h->have_scene || h->frame_int.empty()) return false;
+    h->last_error = "the uploaded scene's frames were renumbered for one rank; configure the exchange before the upload";
+    return true;
+}
+
 int srk_ba_set_allreduce(srk_ba* h, srk_allreduce_fn fn, void* ctx, int rank, int world_size)
 {
     if (!h || world_size < 1 || rank < 0 || rank >= world_size) return SRK_E_ARGS;
+    if (exchange_after_reordered_upload(h, world_size)) return SRK_E_STATE;
     // either exchange replaces the other: exchange() prefers a communicator, so a callback set after srk_ba_rccl_init
     // would never be called unless the communicators are detached here
     if (h->comm || h->comm2) {
@@ -398,6 +413,10 @@ int srk_ba_rccl_get_unique_id(void* id128)
 }
 static int rccl_attach(srk_ba* h, ncclComm_t comm, bool owned, int rank, int world_size)
 {
+    if (exchange_after_reordered_upload(h, world_size)) {
+        if (owned) rccl().CommDestroy(comm);
+        return SRK_E_STATE;
+    }
     if (h->comm && h->comm_owned) rccl().CommDestroy(h->comm);
     if (h->comm2) rccl().CommDestroy(h->comm2);
     h->comm2 = nullptr;
@@ -749,6 +768,106 @@ static int build_envelope(srk_ba* h)
     return SRK_OK;
 }
 
+// Internal frame order.  The reference treats the reduced camera system as a dense matrix (bundle-adj-kanatani.cpp:1911), so
+// the order of the frames means nothing to it.  Here everything fast depends on covisible frames having NEARBY indices: the
+// skyline of the system, its nested dissection (separators one bandwidth wide), the frame windows of the derivative kernels.
+// An image sequence in time order has that property; the same frames in any other order (an unordered image set), or a
+// sequence that closes a loop (the last frames see the first frames' landmarks), do not -- the solve alone then takes 5x
+// longer on the 1000-frame scene (one skyline chain instead of chunks).  So, when the caller's order is far from banded,
+// the frames are renumbered by reverse Cuthill-McKee on the covisibility graph (two frames adjacent iff they share a
+// landmark), started from a pseudo-peripheral frame: a shuffled sequence gets its band back, a closed loop becomes a band
+// of two to three times the width (twice is the optimum for a ring).  Only the numbering changes -- arithmetic per block, gauge (the caller's frames 0 and 1, wherever they
+// land: SrkDims::g0, g1) and results are those of the caller's order; every download maps back.
+// Returns true and fills to_int[caller's frame] = internal index when renumbering pays.  mode: see srk_ba::frame_order_mode.
+static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* obs_frame, std::vector<int32_t>& to_int)
+{
+    if (mode == 0 || M < 3 || M > 16384) return false;
+    int64_t bw_nat = 0, lmax = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t k = row_ptr[i + 1] - row_ptr[i];
+        if (k < 1) continue;
+        lmax = std::max(lmax, k);
+        bw_nat = std::max<int64_t>(bw_nat, obs_frame[row_ptr[i + 1] - 1] - obs_frame[row_ptr[i]]); // lists ascend
+    }
+    if (mode < 0 && bw_nat <= 2 * lmax) return false; // as banded as tracks of that length allow
+    // covisibility graph as a bit matrix (M <= 16384: 32 MB); every distinct frame list once
+    const size_t wpr = ((size_t)M + 63) / 64;
+    std::vector<uint64_t> adj((size_t)M * wpr, 0);
+    std::unordered_set<uint64_t> seen;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t k = row_ptr[i + 1] - row_ptr[i];
+        if (k < 2) continue;
+        const int32_t* f = obs_frame + row_ptr[i];
+        uint64_t hsh = 1469598103934665603ull ^ (uint64_t)k;
+        for (int64_t a = 0; a < k; ++a) hsh = (hsh ^ (uint64_t)(uint32_t)f[a]) * 1099511628211ull;
+        if (!seen.insert(hsh).second) continue; // (a collision only costs ordering quality: the skyline is built from the observations)
+        for (int64_t a = 0; a < k; ++a)
+            for (int64_t b = a + 1; b < k; ++b) {
+                adj[(size_t)f[a] * wpr + (size_t)(f[b] >> 6)] |= 1ull << (f[b] & 63);
+                adj[(size_t)f[b] * wpr + (size_t)(f[a] >> 6)] |= 1ull << (f[a] & 63);
+            }
+    }
+    std::vector<int32_t> deg((size_t)M, 0);
+    for (int32_t j = 0; j < M; ++j)
+        for (size_t w = 0; w < wpr; ++w) deg[(size_t)j] += __builtin_popcountll(adj[(size_t)j * wpr + w]);
+    std::vector<int32_t> order, level((size_t)M), nb;
+    std::vector<char> done((size_t)M, 0);
+    // breadth-first levels of the component of `root` among the frames not yet numbered; returns the last level's
+    // frame of smallest degree and the depth
+    auto bfs = [&](int32_t root, std::vector<int32_t>& out, int32_t& depth) -> int32_t {
+        out.clear();
+        out.push_back(root);
+        std::vector<char> vis(done);
+        vis[(size_t)root] = 1;
+        level[(size_t)root] = 0;
+        for (size_t q = 0; q < out.size(); ++q) {
+            const int32_t u = out[q];
+            nb.clear();
+            for (size_t w = 0; w < wpr; ++w)
+                for (uint64_t bits = adj[(size_t)u * wpr + w]; bits; bits &= bits - 1) {
+                    const int32_t v = (int32_t)(64 * w) + __builtin_ctzll(bits);
+                    if (!vis[(size_t)v]) { vis[(size_t)v] = 1; nb.push_back(v); }
+                }
+            std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return deg[(size_t)a] != deg[(size_t)b] ? deg[(size_t)a] < deg[(size_t)b] : a < b; });
+            for (int32_t v : nb) { level[(size_t)v] = level[(size_t)u] + 1; out.push_back(v); }
+        }
+        depth = level[(size_t)out.back()];
+        int32_t far = out.back();
+        for (size_t q = out.size(); q-- > 0 && level[(size_t)out[q]] == depth;)
+            if (deg[(size_t)out[q]] < deg[(size_t)far] || (deg[(size_t)out[q]] == deg[(size_t)far] && out[q] < far)) far = out[q];
+        return far;
+    };
+    std::vector<int32_t> comp;
+    for (int32_t start = 0; start < M; ++start) {
+        if (done[(size_t)start]) continue;
+        int32_t root = start, depth = -1, d2 = 0;
+        for (int it = 0; it < 4; ++it) { // George-Liu: walk to a frame of (nearly) greatest eccentricity
+            const int32_t far = bfs(root, comp, d2);
+            if (d2 <= depth) break;
+            depth = d2;
+            root = far;
+        }
+        bfs(root, comp, d2);
+        for (int32_t v : comp) { done[(size_t)v] = 1; order.push_back(v); }
+    }
+    std::reverse(order.begin(), order.end());
+    to_int.assign((size_t)M, 0);
+    for (int32_t i = 0; i < M; ++i) to_int[(size_t)order[(size_t)i]] = i;
+    int64_t bw_new = 0;
+    bool differs = false;
+    for (int32_t j = 0; j < M; ++j) differs = differs || to_int[(size_t)j] != j;
+    for (int64_t i = 0; i < N; ++i) {
+        int32_t lo = M, hi = -1;
+        for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o) {
+            lo = std::min(lo, to_int[(size_t)obs_frame[o]]);
+            hi = std::max(hi, to_int[(size_t)obs_frame[o]]);
+        }
+        if (hi >= 0) bw_new = std::max<int64_t>(bw_new, hi - lo);
+    }
+    if (srk_debug()) fprintf(stderr, "srk_ba frame order: bandwidth %lld frames in the caller's order, %lld after reverse Cuthill-McKee\n", (long long)bw_nat, (long long)bw_new);
+    return mode > 0 ? differs : 10 * bw_new <= 7 * bw_nat;
+}
+
 extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
                                    const double* cam_R_in, const double* cam_T_in, const double* K_in, int shared_k,
                                    const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
@@ -777,6 +896,53 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     }
     std::vector<double> Kexp(9 * (int64_t)M);
     for (int32_t j = 0; j < M; ++j) std::memcpy(&Kexp[9 * (int64_t)j], shared_k ? K_in : K_in + 9 * (int64_t)j, 72);
+
+    // ---- internal frame order (frame_reorder above; one rank only: shards would each find another order)
+    std::vector<int32_t> of_fr;
+    std::vector<double> ouv_fr;
+    h->frame_int.clear();
+    h->frame_user.clear();
+    h->obs_rank.clear();
+    int32_t g0 = 0, g1 = 1;
+    {
+        std::vector<int32_t> to_int;
+        if (!(h->allreduce || h->comm) && frame_reorder(h->frame_order_mode, N, M, row_ptr, obs_frame, to_int)) {
+            h->frame_int = to_int;
+            h->frame_user.assign((size_t)M, 0);
+            for (int32_t j = 0; j < M; ++j) h->frame_user[(size_t)to_int[(size_t)j]] = j;
+            g0 = to_int[0];
+            g1 = to_int[1];
+            // cameras in the internal order; every landmark's observations re-sorted by internal frame
+            std::vector<double> r2(camR.size()), t2(camT.size()), k2(Kexp.size());
+            for (int32_t j = 0; j < M; ++j) {
+                const int64_t u = h->frame_user[(size_t)j];
+                std::memcpy(&r2[9 * (size_t)j], &camR[9 * (size_t)u], 72);
+                std::memcpy(&t2[3 * (size_t)j], &camT[3 * (size_t)u], 24);
+                std::memcpy(&k2[9 * (size_t)j], &Kexp[9 * (size_t)u], 72);
+            }
+            camR.swap(r2);
+            camT.swap(t2);
+            Kexp.swap(k2);
+            of_fr.resize((size_t)O);
+            ouv_fr.resize((size_t)(2 * O));
+            h->obs_rank.resize((size_t)O);
+            std::vector<std::pair<int32_t, int64_t>> key;
+            for (int64_t i = 0; i < N; ++i) {
+                key.clear();
+                for (int64_t o = row_ptr[i]; o < row_ptr[i + 1]; ++o) key.emplace_back(to_int[(size_t)obs_frame[o]], o);
+                std::sort(key.begin(), key.end());
+                for (size_t a = 0; a < key.size(); ++a) {
+                    const int64_t dst = row_ptr[i] + (int64_t)a, src = key[a].second;
+                    of_fr[(size_t)dst] = key[a].first;
+                    ouv_fr[(size_t)(2 * dst)] = obs_uv[2 * src];
+                    ouv_fr[(size_t)(2 * dst + 1)] = obs_uv[2 * src + 1];
+                    h->obs_rank[(size_t)src] = (int32_t)a;
+                }
+            }
+            obs_frame = of_fr.data();
+            obs_uv = ouv_fr.data();
+        }
+    }
 
     // ---- internal landmark order: sorted by frame list, so that landmarks seeing exactly the same frames are
     // contiguous (the grouped Schur kernel accumulates a run of them in registers and flushes once)
@@ -935,6 +1101,8 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     if (d.Ns == 0) d.Ns = 64;
     d.ld = ((10 * (int64_t)M + SRK_CHOL_NB - 1) / SRK_CHOL_NB) * SRK_CHOL_NB;
     d.comp = 1;
+    d.g0 = g0;
+    d.g1 = g1;
     d.w_f32 = h->store_f32 ? 1 : 0;
     h->d = d;
     h->f0 = f0;
@@ -1198,6 +1366,15 @@ static int clear_poison(srk_ba* h)
     return SRK_OK;
 }
 
+// a per-frame array of `w` doubles per frame, just downloaded in the internal frame order -> the caller's order
+static void frames_to_user(const srk_ba* h, double* a, int w)
+{
+    if (h->frame_int.empty()) return;
+    const int32_t M = h->d.M;
+    std::vector<double> tmp(a, a + (size_t)w * (size_t)M);
+    for (int32_t j = 0; j < M; ++j) std::memcpy(a + (size_t)w * (size_t)j, &tmp[(size_t)w * (size_t)h->frame_int[(size_t)j]], (size_t)(8 * w));
+}
+
 extern "C" int srk_ba_reset_scene(srk_ba* h)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
@@ -1228,6 +1405,8 @@ extern "C" int srk_ba_download_scene(srk_ba* h, double* pts, double* cam_R, doub
     HIPCHK(h, hipMemcpyAsync(cam_R, h->camR[c].p, 72 * (int64_t)h->d.M, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(cam_T, h->camT[c].p, 24 * (int64_t)h->d.M, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    frames_to_user(h, cam_R, 9);
+    frames_to_user(h, cam_T, 3);
     for (int64_t i = 0; i < h->d.N; ++i) std::memcpy(pts + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
     if (revert && h->normalized_on_upload) srk_ba_revert_normalization(h->d.N, pts, h->d.M, cam_R, cam_T, &h->nrm); // :706
     return SRK_OK;
@@ -2307,6 +2486,7 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
         if ((rc = d2h(ug.data(), h->Ug.p, ug.size() * 8)) != SRK_OK) return rc;
         for (int32_t j = 0; j < d.M; ++j)
             for (int e = 0; e < 10; ++e) dst[3 * d.N + 10 * (int64_t)j + e] = ug[(size_t)(SRK_UG * (int64_t)j + 55 + e)];
+        frames_to_user(h, dst + 3 * d.N, 10);
         return SRK_OK;
     }
     case SRK_BUF_FRAME_BLOCKS: {
@@ -2318,6 +2498,7 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
                     int a = v1 < v2 ? v1 : v2, b = v1 < v2 ? v2 : v1;
                     dst[100 * (int64_t)j + 10 * v1 + v2] = ug[(size_t)(SRK_UG * (int64_t)j + a * 10 - a * (a - 1) / 2 + (b - a))];
                 }
+        frames_to_user(h, dst, 100);
         return SRK_OK;
     }
     case SRK_BUF_POINT_FRAME: {
@@ -2342,29 +2523,39 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
         for (int64_t i = 0; i < d.N; ++i) {
             int64_t oi = h->row_ptr_int[(size_t)i], ou = h->row_ptr_user[(size_t)h->perm[(size_t)i]];
             int64_t cnt = h->row_ptr_int[(size_t)i + 1] - oi;
-            for (int64_t a = 0; a < cnt; ++a)
-                for (int k = 0; k < 30; ++k) dst[30 * (ou + a) + k] = w[(size_t)(k * d.Os + oi + a)];
+            for (int64_t a = 0; a < cnt; ++a) { // the caller's observation ou + a: internal place obs_rank inside its landmark
+                const int64_t ai = h->obs_rank.empty() ? a : h->obs_rank[(size_t)(ou + a)];
+                for (int k = 0; k < 30; ++k) dst[30 * (ou + a) + k] = w[(size_t)(k * d.Os + oi + ai)];
+            }
         }
         return SRK_OK;
     }
     case SRK_BUF_RCS: {
         int64_t n = 10 * (int64_t)d.M;
         std::vector<double> row((size_t)d.ld);
+        auto uvar = [&](int64_t v) { return h->frame_user.empty() ? v : 10 * (int64_t)h->frame_user[(size_t)(v / 10)] + v % 10; };
         for (int64_t r = 0; r < n; ++r) {
             if ((rc = d2h(row.data(), P<double>(h->A->S) + r * d.ld, (size_t)(8 * n))) != SRK_OK) return rc;
+            const int64_t ur = uvar(r);
             for (int64_t c = 0; c <= r; ++c) {
-                dst[r * n + c] = row[(size_t)c];
-                dst[c * n + r] = row[(size_t)c]; // lower triangle is authoritative
+                const int64_t uc = uvar(c);
+                dst[ur * n + uc] = row[(size_t)c];
+                dst[uc * n + ur] = row[(size_t)c]; // lower triangle is authoritative
             }
         }
         return SRK_OK;
     }
-    case SRK_BUF_RCS_RHS: return d2h(dst, h->A->rhs.p, (size_t)(80 * (int64_t)d.M));
+    case SRK_BUF_RCS_RHS:
+        if ((rc = d2h(dst, h->A->rhs.p, (size_t)(80 * (int64_t)d.M))) != SRK_OK) return rc;
+        frames_to_user(h, dst, 10);
+        return SRK_OK;
     case SRK_BUF_CORRECTIONS: {
         std::vector<double> tmp((size_t)(3 * d.N));
         if ((rc = d2h(tmp.data(), h->A->dx.p, (size_t)(24 * d.N))) != SRK_OK) return rc;
         for (int64_t i = 0; i < d.N; ++i) std::memcpy(dst + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
-        return d2h(dst + 3 * d.N, h->A->dc.p, (size_t)(80 * (int64_t)d.M));
+        if ((rc = d2h(dst + 3 * d.N, h->A->dc.p, (size_t)(80 * (int64_t)d.M))) != SRK_OK) return rc;
+        frames_to_user(h, dst + 3 * d.N, 10);
+        return SRK_OK;
     }
     case SRK_BUF_POINTS: {
         std::vector<double> tmp((size_t)(3 * d.N));
@@ -2372,8 +2563,14 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
         for (int64_t i = 0; i < d.N; ++i) std::memcpy(dst + 3 * h->perm[(size_t)i], &tmp[(size_t)(3 * i)], 24);
         return SRK_OK;
     }
-    case SRK_BUF_CAM_R: return d2h(dst, h->camR[h->cur].p, (size_t)(72 * (int64_t)d.M));
-    case SRK_BUF_CAM_T: return d2h(dst, h->camT[h->cur].p, (size_t)(24 * (int64_t)d.M));
+    case SRK_BUF_CAM_R:
+        if ((rc = d2h(dst, h->camR[h->cur].p, (size_t)(72 * (int64_t)d.M))) != SRK_OK) return rc;
+        frames_to_user(h, dst, 9);
+        return SRK_OK;
+    case SRK_BUF_CAM_T:
+        if ((rc = d2h(dst, h->camT[h->cur].p, (size_t)(24 * (int64_t)d.M))) != SRK_OK) return rc;
+        frames_to_user(h, dst, 3);
+        return SRK_OK;
     default: return SRK_E_ARGS;
     }
 }
@@ -2387,11 +2584,27 @@ int srk_ba_download_rcs_rows(srk_ba* h, const int64_t* rows, int64_t n_rows, dou
     const SrkDims& d = h->d;
     const int64_t n = 10 * (int64_t)d.M;
     const double* S = P<double>(h->att[h->last_slot].S);
+    std::vector<double> rowi, coli;
     for (int64_t k = 0; k < n_rows; ++k) {
         const int64_t r = rows[k];
         if (r < 0 || r >= n) { h->last_error = "download_rcs_rows: row out of range"; return SRK_E_ARGS; }
         std::memset(dst + k * n, 0, (size_t)(8 * n));
-        HIPCHK(h, hipMemcpy(dst + k * n, S + r * d.ld, (size_t)(8 * (r + 1)), hipMemcpyDeviceToHost));
+        if (h->frame_int.empty()) {
+            HIPCHK(h, hipMemcpy(dst + k * n, S + r * d.ld, (size_t)(8 * (r + 1)), hipMemcpyDeviceToHost));
+            continue;
+        }
+        // reordered frames: the caller's row r is internal row ri; its entries left of the diagonal in the CALLER's order
+        // lie in internal row ri (internal columns <= ri) and in internal column ri (rows > ri)
+        const int64_t ri = 10 * (int64_t)h->frame_int[(size_t)(r / 10)] + r % 10;
+        rowi.assign((size_t)n, 0.0);
+        coli.assign((size_t)n, 0.0);
+        HIPCHK(h, hipMemcpy(rowi.data(), S + ri * d.ld, (size_t)(8 * (ri + 1)), hipMemcpyDeviceToHost));
+        if (ri + 1 < n)
+            HIPCHK(h, hipMemcpy2D(coli.data() + ri + 1, 8, S + (ri + 1) * d.ld + ri, (size_t)(8 * d.ld), 8, (size_t)(n - ri - 1), hipMemcpyDeviceToHost));
+        for (int64_t ci = 0; ci < n; ++ci) {
+            const int64_t c = 10 * (int64_t)h->frame_user[(size_t)(ci / 10)] + ci % 10;
+            if (c <= r) dst[k * n + c] = ci <= ri ? rowi[(size_t)ci] : coli[(size_t)ci];
+        }
     }
     return SRK_OK;
 }
@@ -2467,6 +2680,10 @@ int srk_ba_set_covisibility(srk_ba* h, const int32_t* min_cv)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
     HIPCHK(h, hipSetDevice(h->device));
+    if (min_cv && !h->frame_int.empty()) { // (a covisibility in the caller's numbering says nothing about the internal one)
+        h->last_error = "set_covisibility: the frames of this scene were renumbered (srk_ba_set_frame_reordering 0 keeps the caller's order)";
+        return SRK_E_STATE;
+    }
     if (min_cv) {
         for (int32_t j = 0; j < h->d.M; ++j) {
             if (min_cv[j] < 0 || min_cv[j] > j) { h->last_error = "min_cv[j] must be in [0, j]"; return SRK_E_ARGS; }
@@ -2524,6 +2741,31 @@ int srk_ba_set_speculation(srk_ba* h, int on)
     if (!h || (on != 0 && on != 1)) return SRK_E_ARGS;
     h->speculate = on != 0; // takes effect at the next upload (the second attempt slot is allocated there)
     return SRK_OK;
+}
+
+// internal frame order (frame_reorder): -1 = automatic (renumber when the caller's order is far from banded), 0 = never,
+// 1 = whenever reverse Cuthill-McKee gives another order than the caller's; takes effect at the next upload
+int srk_ba_set_frame_reordering(srk_ba* h, int mode)
+{
+    if (!h || mode < -1 || mode > 1) return SRK_E_ARGS;
+    h->frame_order_mode = mode;
+    return SRK_OK;
+}
+// 1 = the uploaded scene's frames are stored in another order (to_internal[caller's frame] filled when not NULL), 0 = the caller's order
+int srk_ba_frame_order(srk_ba* h, int32_t* to_internal)
+{
+    if (!h || !h->have_scene) return SRK_E_STATE;
+    for (int32_t j = 0; to_internal && j < h->d.M; ++j) to_internal[j] = h->frame_int.empty() ? j : h->frame_int[(size_t)j];
+    return h->frame_int.empty() ? 0 : 1;
+}
+// the ordering alone (host only, no device needed): what srk_ba_upload_scene would decide for these tracks
+int srk_frame_order(int mode, int64_t N, int32_t M, const int64_t* row_ptr, const int32_t* obs_frame, int32_t* to_internal)
+{
+    if (N < 0 || M < 1 || !row_ptr || (row_ptr[N] > 0 && !obs_frame) || !to_internal) return SRK_E_ARGS;
+    std::vector<int32_t> to_int;
+    const bool on = frame_reorder(mode, N, M, row_ptr, obs_frame, to_int);
+    for (int32_t j = 0; j < M; ++j) to_internal[j] = on ? to_int[(size_t)j] : j;
+    return on ? 1 : 0;
 }
 
 // -1 = automatic (run-based kernel when the runs of identical frame lists are long enough), 0 = per-observation kernels

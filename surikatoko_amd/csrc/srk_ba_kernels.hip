@@ -14,10 +14,12 @@
 
 #define WAVE 64
 
-__device__ __forceinline__ bool srk_is_fixed_var(int64_t var, int comp)
+__device__ __forceinline__ bool srk_is_fixed_var(int64_t var, const SrkDims& d)
 {
-    // bundle-adj-kanatani.cpp:539-563: frame-local 4..9 of frame 0 and 14+comp are removed by the gauge
-    return (var >= 4 && var <= 9) || (var == 14 + comp);
+    // bundle-adj-kanatani.cpp:539-563: frame-local 4..9 of frame 0 and 14+comp (frame 1's 4+comp) are removed by the gauge;
+    // d.g0, d.g1: where the caller's frames 0 and 1 sit in the internal frame order (0 and 1 unless the frames were reordered)
+    const int64_t b0 = 10 * (int64_t)d.g0;
+    return (var >= b0 + 4 && var <= b0 + 9) || (var == 10 * (int64_t)d.g1 + 4 + d.comp);
 }
 
 // ------------------------------------------------------------------ camera pack
@@ -859,7 +861,7 @@ __device__ __forceinline__ void schur_one_landmark(const SrkDims& d, double c, c
         for (int t = threadIdx.x; t < na * 10; t += 256) {
             int a = t / 10, r = t - a * 10;
             int64_t row = 10 * (int64_t)sFa[a] + r;
-            if (!srk_is_fixed_var(row, d.comp)) {
+            if (!srk_is_fixed_var(row, d)) {
                 double v = sWa[a][r] * Eg[0] + sWa[a][10 + r] * Eg[1] + sWa[a][20 + r] * Eg[2];
                 atomicAdd(&rhs[row], v);
             }
@@ -886,7 +888,7 @@ __device__ __forceinline__ void schur_one_landmark(const SrkDims& d, double c, c
                 if (ca == cb && b > a) continue; // lower block triangle only (frames ascend inside a landmark)
                 int r = e / 10, cc = e - r * 10;
                 int64_t row = 10 * (int64_t)sFa[a] + r, col = 10 * (int64_t)sFb[b] + cc;
-                if (srk_is_fixed_var(row, d.comp) || srk_is_fixed_var(col, d.comp)) continue;
+                if (srk_is_fixed_var(row, d) || srk_is_fixed_var(col, d)) continue;
                 double v = sWa[a][r] * sYb[b][cc] + sWa[a][10 + r] * sYb[b][10 + cc] + sWa[a][20 + r] * sYb[b][20 + cc];
                 atomicAdd(&S[row * d.ld + col], -v); // S = G - sum F^T E^-1 F  (:1891-1892)
             }
@@ -1188,13 +1190,13 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
                 const int a = a0 + rho / 10, r = rho - 10 * (a - a0);
                 const int w = 10 * (a + 1);
                 const int64_t row = 10 * (int64_t)sF[a] + r;
-                if (srk_is_fixed_var(row, d.comp)) continue;
+                if (srk_is_fixed_var(row, d)) continue;
                 const T* src = sBuf + 50 * (a * (a + 1) - a0 * (a0 + 1)) + r * w;
                 double* dst = S + row * d.ld;
                 for (int cw = lane; cw < w; cw += 64) {
                     const int b = cw / 10, cc = cw - b * 10;
                     const int64_t col = 10 * (int64_t)sF[b] + cc;
-                    if (srk_is_fixed_var(col, d.comp)) continue;
+                    if (srk_is_fixed_var(col, d)) continue;
 #ifdef SRK_SCH_NOFLUSH
                     if (d.N >= 0) continue;
 #endif
@@ -1209,7 +1211,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_grouped(
         if (ypl[i] >= SRK_GRP_PB || ypl[i] >= np) continue; // a slot that never held a landmark
         int a = yrow[i] / 10, r = yrow[i] - a * 10;
         int64_t row = 10 * (int64_t)sF[a] + r;
-        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], racc[i]);
+        if (!srk_is_fixed_var(row, d)) atomicAdd(&rhs[row], racc[i]);
     }
 }
 
@@ -1264,13 +1266,13 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
             const int a = a0 + rho / 10, r = rho - 10 * (a - a0);
             const int w = 10 * (a + 1);
             const int64_t row = 10 * (int64_t)sF[a] + r;
-            if (srk_is_fixed_var(row, d.comp)) continue;
+            if (srk_is_fixed_var(row, d)) continue;
             const T* src = sBuf + 50 * (a * (a + 1) - a0 * (a0 + 1)) + r * w;
             double* dst = S + row * d.ld;
             for (int cw = lane; cw < w; cw += 64) {
                 const int b = cw / 10, cc = cw - b * 10;
                 const int64_t col = 10 * (int64_t)sF[b] + cc;
-                if (srk_is_fixed_var(col, d.comp)) continue;
+                if (srk_is_fixed_var(col, d)) continue;
 #ifdef SRK_SCH_NOFLUSH
                 if (d.N >= 0) continue;
 #endif
@@ -1446,7 +1448,7 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
     if (tid < nf10) {
         const int a = tid / 10, r = tid - a * 10;
         const int64_t row = 10 * (int64_t)sF[a] + r;
-        if (!srk_is_fixed_var(row, d.comp)) atomicAdd(&rhs[row], sRhs[tid]);
+        if (!srk_is_fixed_var(row, d)) atomicAdd(&rhs[row], sRhs[tid]);
     }
 }
 
@@ -1629,7 +1631,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     if (tid < nf * 10) {
         sRhs[tid] = 0.0;
         const int64_t var = 10 * (int64_t)grp_frames[(int64_t)blockIdx.x * SRK_GRP_MAXNF + tid / 10] + tid % 10;
-        sVar[tid] = srk_is_fixed_var(var, d.comp) ? -1 : (int)var;
+        sVar[tid] = srk_is_fixed_var(var, d) ? -1 : (int)var;
     }
     const int R = (np + PB - 1) / PB;
     const int nf10 = nf * 10;
@@ -2282,7 +2284,7 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
         int var = -1;
         if (slot < nf) {
             const int64_t v = 10 * (int64_t)run_frames[(int64_t)run * SRK_LONG_MAXNF_HOST + slot] + e % 10;
-            var = srk_is_fixed_var(v, d.comp) ? -1 : (int)v;
+            var = srk_is_fixed_var(v, d) ? -1 : (int)v;
         }
         sVar[side][e] = var;
     }
@@ -2482,7 +2484,7 @@ __global__ __launch_bounds__(256) void k_assemble(SrkDims d, double c, const dou
         if (e < 100) {
             int v1 = e / 10, v2 = e - v1 * 10;
             int64_t row = 10 * j + v1, col = 10 * j + v2;
-            bool fr = srk_is_fixed_var(row, d.comp), fc = srk_is_fixed_var(col, d.comp);
+            bool fr = srk_is_fixed_var(row, d), fc = srk_is_fixed_var(col, d);
             if (fr || fc) {
                 if (v1 == v2) S[row * d.ld + col] = ident;
             } else {
@@ -2494,7 +2496,7 @@ __global__ __launch_bounds__(256) void k_assemble(SrkDims d, double c, const dou
         } else {
             int v = e - 100;
             int64_t row = 10 * j + v;
-            if (srk_is_fixed_var(row, d.comp)) rhs[row] = 0.0;
+            if (srk_is_fixed_var(row, d)) rhs[row] = 0.0;
             else rhs[row] -= u[55 + v];
         }
     } else {

@@ -40,6 +40,7 @@ struct SrkDims {
     int64_t ld;          // padded RCS dimension (multiple of SRK_CHOL_NB)
     int32_t comp;        // unity_t1_comp_ind (gauge), 1 by default
     int32_t w_f32;       // 1: the point-frame blocks W are stored as float (W then points at floats), arithmetic stays fp64
+    int32_t g0, g1;      // internal indices of the caller's frames 0 and 1 (the gauge-fixed ones): 0, 1 unless the frames were reordered
 };
 
 #define SRK_CHOL_NB 256 // outer panel of the blocked Cholesky; ld is a multiple of it

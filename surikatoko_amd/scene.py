@@ -115,3 +115,38 @@ def drop_observations(scene, fraction, seed=0, keep_min=2):
     new_rp = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     return Scene(scene.points, scene.cam_R, scene.cam_T, scene.K, scene.shared_k, new_rp, scene.obs_frame[keep],
                  scene.obs_uv[keep])
+
+
+def renumber_frames(scene, new_index):
+    """The same scene with its frames numbered differently: frame j becomes frame new_index[j] (cameras and intrinsics
+    move with it, every landmark's observations are re-sorted by the new index).  What an unordered image set looks like
+    to the solver; the reference (a dense system, bundle-adj-kanatani.cpp:1911) is indifferent to it."""
+    import numpy as np
+    from .ba import Scene
+    new_index = np.asarray(new_index, np.int64)
+    M = scene.M
+    assert sorted(new_index.tolist()) == list(range(M))
+    old_of_new = np.argsort(new_index)
+    K = scene.K if scene.shared_k else scene.K[old_of_new]
+    f = new_index[scene.obs_frame]
+    lm = np.repeat(np.arange(scene.N), np.diff(scene.row_ptr))
+    order = np.lexsort((f, lm))  # by landmark, then by new frame index
+    return Scene(scene.points, scene.cam_R[old_of_new], scene.cam_T[old_of_new], K, scene.shared_k, scene.row_ptr,
+                 f[order].astype(np.int32), scene.obs_uv[order])
+
+
+def loop_scene(spec: SceneSpec, window):
+    """A sequence that closes a loop: the all-visible scene of `spec` (vis_window 0) cut down so that landmark i is seen by
+    the `window` cyclically consecutive frames starting at a pseudo-random frame -- the last frames share landmarks with
+    the first ones, so the reduced camera system is a band plus two corner blocks."""
+    import numpy as np
+    from .ba import Scene
+    assert spec.vis_window == 0
+    sc = generate_scene(spec)
+    M, N = sc.M, sc.N
+    assert np.all(np.diff(sc.row_ptr) == M) and 2 <= window < M
+    start = (np.arange(N, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(2 ** 32) % np.uint64(M)).astype(np.int64)
+    frames = np.sort((start[:, None] + np.arange(window)[None, :]) % M, axis=1)  # [N, window] ascending
+    idx = (np.arange(N)[:, None] * M + frames).ravel()
+    row_ptr = np.arange(N + 1, dtype=np.int64) * window
+    return Scene(sc.points, sc.cam_R, sc.cam_T, sc.K, sc.shared_k, row_ptr, frames.ravel().astype(np.int32), sc.obs_uv[idx])

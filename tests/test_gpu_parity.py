@@ -1485,3 +1485,86 @@ def test_speculative_attempts_follow_the_sequential_loop(orc, name):
     so = _orc_scene(orc, sc)
     rc_o, rep_o = orc.compute_inplace(spec.f0, so, 1e-9, None, 12)
     assert (a[1], a[2]) == (rep_o.iterations, rep_o.attempts) and a[0] == (rc_o == 0)
+
+
+# ------------------------------------------------------------------ frames in another order than time (srk_ba_set_frame_reordering)
+
+def _shuffled(spec, seed, drop=0.0):
+    sc = sa.generate_scene(spec)
+    if drop:
+        sc = sa.drop_observations(sc, drop, seed=seed)
+    return sa.renumber_frames(sc, np.random.RandomState(seed).permutation(sc.M))
+
+
+UNORDERED = {
+    # an unordered image set: the band is there, the numbering hides it
+    "shuffled_60": lambda: _shuffled(sa.SceneSpec(n_frames=60, grid_nx=20, grid_ny=15, vis_window=6, noise_uv_pix=0.3), 1),
+    "shuffled_ragged_45": lambda: _shuffled(sa.SceneSpec(n_frames=45, grid_nx=24, grid_ny=18, vis_window=9), 2, drop=0.3),
+    # a sequence that closes a loop: band + corner blocks
+    "loop_90": lambda: sa.loop_scene(sa.SceneSpec(n_frames=90, grid_nx=20, grid_ny=15, vis_window=0), window=6),
+}
+
+
+@pytest.mark.parametrize("name", list(UNORDERED))
+@pytest.mark.parametrize("c", [1e-4, 10.0])
+def test_phases_with_renumbered_frames_vs_oracle(orc, gpu, name, c):
+    """The frames are renumbered inside (reverse Cuthill-McKee), the gauge stays on the caller's frames 0 and 1, every
+    download comes back in the caller's order: the same checks as for any other scene, against the oracle run on the
+    caller's numbering (the reference's dense system does not care, bundle-adj-kanatani.cpp:1911)."""
+    sc = UNORDERED[name]()
+    out = _phases(orc, gpu, sc, 600.0, c)
+    to_int = gpu.frame_order()
+    assert to_int is not None and sorted(to_int.tolist()) == list(range(sc.M))
+    _check(out, sc.M)
+    # selected rows of the system come back in the caller's numbering too
+    rows = np.array([0, 3, 10, 16, 10 * sc.M - 1, 10 * (sc.M // 2) + 7], np.int64)
+    gpu.phase_schur(c)
+    full = gpu.buffer(B.BUF_RCS).reshape(10 * sc.M, 10 * sc.M)
+    assert np.array_equal(gpu.rcs_rows(rows), np.tril(full)[rows])
+
+
+@pytest.mark.parametrize("name", list(UNORDERED))
+def test_compute_inplace_with_renumbered_frames_matches_oracle(orc, gpu, name):
+    sc = UNORDERED[name]()
+    rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, 600.0, allowed=1e-10, max_factor=1e6, max_iterations=12)
+    assert gpu.frame_order() is not None
+    assert ok == (rc_o == 0) and sa.status_string(rep.status) == orc.status_string(rep_o.status)
+    assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts) and rep.iterations >= 1
+    assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6, abs=1e-18)
+    assert np.abs(sg.points - so.points).max() < 1e-6
+    assert np.abs(sg.cam_R - so.cam_R).max() < 1e-6
+    assert np.abs(sg.cam_T - so.cam_T).max() < 1e-6
+
+
+def test_renumbering_gives_an_unordered_400_frame_scene_its_chunked_solve_back():
+    """400 frames, 20-frame tracks, frame numbers shuffled: in the caller's order the skyline is nearly the full triangle
+    and the solve is one chain; renumbered, the system is the band of the time-ordered sequence again and is cut into
+    chunks.  Both runs take the same decisions and end in the same scene."""
+    spec = sa.SceneSpec(n_frames=400, grid_nx=80, grid_ny=50, vis_window=20, noise_uv_pix=0.2)
+    sc = _shuffled(spec, 7)
+    res = {}
+    ba = sa.BundleAdjustmentKanatani(0)
+    try:
+        for mode in (0, -1):
+            ba.set_frame_reordering(mode)
+            s2 = sc.copy()
+            ba.ComputeInplace(spec.f0, s2, None, 4)
+            res[mode] = (ba.report.iterations, ba.report.attempts, ba.report.err_final, s2, ba.rcs_chunks(), ba.rcs_fill(),
+                         ba.frame_order())
+        assert res[0][6] is None and res[-1][6] is not None
+        assert res[0][4] == 0 and res[-1][4] >= 2
+        assert res[-1][5] < 0.3 < res[0][5]
+        assert res[0][:2] == res[-1][:2]
+        assert res[-1][2] == pytest.approx(res[0][2], rel=1e-8)
+        assert np.abs(res[-1][3].points - res[0][3].points).max() < 1e-8
+        assert np.abs(res[-1][3].cam_T - res[0][3].cam_T).max() < 1e-8
+        # a time-ordered sequence is left alone; forcing the ordering on it changes nothing but the summation order
+        tm = sa.generate_scene(spec)
+        ba.set_frame_reordering(-1)
+        assert ba.upload(spec.f0, tm) and ba.frame_order() is None
+        # the exchange cannot be configured on a renumbered scene (every shard would find its own numbering)
+        assert ba.upload(spec.f0, sc) and ba.frame_order() is not None
+        with pytest.raises(RuntimeError):
+            ba.set_covisibility(sa.ba.covisibility(sc))
+    finally:
+        ba.close()
