@@ -272,6 +272,10 @@ int srk_ba_set_speculation(srk_ba*, int on);
  * srk_ba_frame_order: 1 = renumbered (to_internal[caller's frame] = internal index, may be NULL), 0 = caller's order.
  * srk_frame_order: the decision and the numbering alone, on the host (no device needed). */
 int srk_ba_set_frame_reordering(srk_ba*, int mode);
+/* The numbering to use at the next upload instead of the automatic one (to_internal = NULL: automatic again).  This is how
+ * landmark shards get a renumbering: the caller finds it on the WHOLE scene (srk_frame_order) and gives every rank the same
+ * one; srk_ba_set_covisibility then takes min_cv in THAT numbering (covisibility of the renumbered scene). */
+int srk_ba_set_frame_order(srk_ba*, const int32_t* to_internal /* [n_frames] or NULL */, int32_t n_frames);
 int srk_ba_frame_order(srk_ba*, int32_t* to_internal /* [M] or NULL */);
 int srk_frame_order(int mode, int64_t n_points, int32_t n_frames, const int64_t* obs_row_ptr, const int32_t* obs_frame,
                     int32_t* to_internal /* [M] */);

@@ -67,16 +67,28 @@ class Scene:
                 C.c_int(self.shared_k), _p(self.row_ptr), _p(self.obs_frame), _p(self.obs_uv))
 
 
-def covisibility(scene):
+def covisibility(scene, to_internal=None):
     """min_cv[j] = smallest frame index that shares a landmark with frame j (the skyline of the reduced camera
-    system); computed on the WHOLE scene before sharding."""
+    system); computed on the WHOLE scene before sharding.  to_internal: the frame numbering given to
+    set_frame_order() -- the result is then in that numbering, as srk_ba_set_covisibility wants it."""
     M = scene.M
-    first = scene.obs_frame[scene.row_ptr[:-1][np.diff(scene.row_ptr) > 0]]
+    f = scene.obs_frame if to_internal is None else np.asarray(to_internal, np.int32)[scene.obs_frame]
     counts = np.diff(scene.row_ptr)
+    first = np.minimum.reduceat(f, scene.row_ptr[:-1][counts > 0]) if scene.O else np.zeros(0, np.int32)
     first_per_obs = np.repeat(first, counts[counts > 0])
     min_cv = np.arange(M, dtype=np.int64)
-    np.minimum.at(min_cv, scene.obs_frame, first_per_obs)
+    np.minimum.at(min_cv, f, first_per_obs)
     return min_cv.astype(np.int32)
+
+
+def frame_order(scene, mode=-1):
+    """srk_frame_order on the host: to_internal[frame] when renumbering the frames pays (mode -1) / differs (mode 1), else
+    None.  For landmark shards: find it on the whole scene, give it to every rank's set_frame_order()."""
+    to_int = np.zeros(scene.M, np.int32)
+    rc = lib().srk_frame_order(C.c_int(mode), C.c_int64(scene.N), C.c_int32(scene.M), _p(scene.row_ptr), _p(scene.obs_frame), _p(to_int))
+    if rc < 0:
+        raise ValueError("srk_frame_order: bad arguments")
+    return to_int if rc == 1 else None
 
 
 def shard_bounds(row_ptr, rank, world):
@@ -284,6 +296,15 @@ class BundleAdjustmentKanatani:
     def set_frame_reordering(self, mode=-1):
         """-1 automatic, 0 = keep the caller's frame order, 1 = renumber whenever the ordering differs (next upload)"""
         self._raise(self._lib.srk_ba_set_frame_reordering(C.c_void_p(self._h), C.c_int(mode)))
+
+    def set_frame_order(self, to_internal=None):
+        """The frame numbering to use at the next upload (None: automatic); landmark shards: the same on every rank, found on
+        the whole scene with surikatoko_amd.frame_order()."""
+        if to_internal is None:
+            self._raise(self._lib.srk_ba_set_frame_order(C.c_void_p(self._h), None, C.c_int32(0)))
+        else:
+            a = np.ascontiguousarray(to_internal, dtype=np.int32)
+            self._raise(self._lib.srk_ba_set_frame_order(C.c_void_p(self._h), _p(a), C.c_int32(a.size)))
 
     def frame_order(self):
         """None when the frames are stored in the caller's order, else to_internal[caller's frame]"""

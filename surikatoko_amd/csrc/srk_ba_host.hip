@@ -62,6 +62,8 @@ struct srk_ba {
     // obs_rank[caller's observation] = its place inside its landmark's internal (re-sorted) observation list.
     std::vector<int32_t> frame_int, frame_user, obs_rank;
     int frame_order_mode = -1; // srk_ba_set_frame_reordering: -1 automatic, 0 never, 1 whenever the ordering differs from the caller's
+    std::vector<int32_t> frame_order_given; // srk_ba_set_frame_order: the numbering to use (several ranks: the same on every rank)
+    bool frame_order_supplied = false;      // the uploaded scene uses frame_order_given
     DevBuf grp_first, grp_count, grp_nf, grp_frames, obs_slot, pt_mask, gen_list, wg_jmin;
     // long tracks (more than SRK_GRP_MAXNF_HOST frames): runs over frame-block pairs, k_schur_long
     DevBuf lg_item, lg_np, lg_nf, lg_pts, lg_frames, lg_obs_off, lg_obs;
@@ -374,7 +376,7 @@ int srk_ba_set_stream(srk_ba* h, void* hip_stream)
 // landmark shards must agree on the frame numbering: each rank's own renumbering (made from its shard at upload) would not
 static bool exchange_after_reordered_upload(srk_ba* h, int world_size)
 {
-    if (world_size < 2 || !h->have_scene || h->frame_int.empty()) return false;
+    if (world_size < 2 || !h->have_scene || h->frame_int.empty() || h->frame_order_supplied) return false;
     h->last_error = "the uploaded scene's frames were renumbered for one rank; configure the exchange before the upload";
     return true;
 }
@@ -906,7 +908,16 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     int32_t g0 = 0, g1 = 1;
     {
         std::vector<int32_t> to_int;
-        if (!(h->allreduce || h->comm) && frame_reorder(h->frame_order_mode, N, M, row_ptr, obs_frame, to_int)) {
+        bool renumber = false;
+        h->frame_order_supplied = false;
+        if (!h->frame_order_given.empty()) {
+            if ((int64_t)h->frame_order_given.size() != (int64_t)M) { h->last_error = "the supplied frame order is for another number of frames"; return SRK_E_ARGS; }
+            to_int = h->frame_order_given;
+            for (int32_t j = 0; j < M; ++j) renumber = renumber || to_int[(size_t)j] != j;
+            h->frame_order_supplied = renumber;
+        } else if (!(h->allreduce || h->comm))
+            renumber = frame_reorder(h->frame_order_mode, N, M, row_ptr, obs_frame, to_int);
+        if (renumber) {
             h->frame_int = to_int;
             h->frame_user.assign((size_t)M, 0);
             for (int32_t j = 0; j < M; ++j) h->frame_user[(size_t)to_int[(size_t)j]] = j;
@@ -2680,7 +2691,9 @@ int srk_ba_set_covisibility(srk_ba* h, const int32_t* min_cv)
 {
     if (!h || !h->have_scene) return SRK_E_STATE;
     HIPCHK(h, hipSetDevice(h->device));
-    if (min_cv && !h->frame_int.empty()) { // (a covisibility in the caller's numbering says nothing about the internal one)
+    // a covisibility in the caller's numbering says nothing about the internal one: with a SUPPLIED frame order
+    // (srk_ba_set_frame_order) min_cv is taken in that numbering, which the caller knows; an automatic one is one rank's own
+    if (min_cv && !h->frame_int.empty() && !h->frame_order_supplied) {
         h->last_error = "set_covisibility: the frames of this scene were renumbered (srk_ba_set_frame_reordering 0 keeps the caller's order)";
         return SRK_E_STATE;
     }
@@ -2749,6 +2762,20 @@ int srk_ba_set_frame_reordering(srk_ba* h, int mode)
 {
     if (!h || mode < -1 || mode > 1) return SRK_E_ARGS;
     h->frame_order_mode = mode;
+    return SRK_OK;
+}
+// the numbering to use at the next upload instead of the automatic one (NULL: automatic again); with landmark shards every
+// rank must be given the same one, found on the WHOLE scene (srk_frame_order)
+int srk_ba_set_frame_order(srk_ba* h, const int32_t* to_internal, int32_t n_frames)
+{
+    if (!h || (to_internal && n_frames < 1)) return SRK_E_ARGS;
+    if (!to_internal) { h->frame_order_given.clear(); return SRK_OK; }
+    std::vector<char> hit((size_t)n_frames, 0);
+    for (int32_t j = 0; j < n_frames; ++j) {
+        if (to_internal[j] < 0 || to_internal[j] >= n_frames || hit[(size_t)to_internal[j]]) { h->last_error = "set_frame_order: not a permutation"; return SRK_E_ARGS; }
+        hit[(size_t)to_internal[j]] = 1;
+    }
+    h->frame_order_given.assign(to_internal, to_internal + n_frames);
     return SRK_OK;
 }
 // 1 = the uploaded scene's frames are stored in another order (to_internal[caller's frame] filled when not NULL), 0 = the caller's order

@@ -15,23 +15,31 @@ def run(rank, world, port, out_dir, spec_kwargs, iters, schedule="dp"):
     os.environ["SRK_DEBUG"] = "1"  # per-attempt trace on stderr: shows up in the pytest log when an assertion fails
     import torch.distributed as dist
     import surikatoko_amd as sa
-    from surikatoko_amd.ba import covisibility, revert_normalization
+    from surikatoko_amd.ba import covisibility, frame_order, revert_normalization
     from surikatoko_amd.dist import make_allreduce_hook
 
     # file rendezvous inside the test's own directory: no TCP port to race for (`port` is kept for the signature)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world,
                             init_method="file://" + os.path.join(out_dir, "rendezvous"))
     try:
+        spec_kwargs = dict(spec_kwargs)
+        shuffle = spec_kwargs.pop("_shuffle", None)
         spec = sa.SceneSpec(**spec_kwargs)
         full = sa.generate_scene(spec)
+        if shuffle is not None:  # an unordered image set: the frame numbers say nothing about covisibility
+            full = sa.renumber_frames(full, np.random.RandomState(shuffle).permutation(full.M))
         ok, nrm = sa.normalize_scene_inplace(full)
         assert ok
         shard, (lo, hi) = full.shard(rank, world)
         ba = sa.BundleAdjustmentKanatani(0)
         hook = make_allreduce_hook(None, "cuda:0")
         ba.set_allreduce(hook, rank, world)
+        # the numbering is found on the WHOLE scene and given to every rank (a shard's own would differ from rank to rank)
+        order = frame_order(full)
+        assert (order is not None) == (shuffle is not None)
+        ba.set_frame_order(order)
         assert ba.upload(spec.f0, shard, already_normalized=True)
-        ba.set_covisibility(covisibility(full))
+        ba.set_covisibility(covisibility(full, order))
         crit = sa.BundleAdjustmentKanataniTermCriteria()
         crit.AllowedReprojErrRelativeChange(1e-7)
         ok = ba.optimize(crit, iters)
