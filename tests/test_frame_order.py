@@ -69,3 +69,17 @@ def test_modes_and_degenerate_inputs():
     assert rc == 1
     empty = sa.Scene(sc.points[:3], sc.cam_R, sc.cam_T, sc.K, sc.shared_k, np.zeros(4, np.int64), np.zeros(0, np.int32), np.zeros((0, 2)))
     assert _order(empty)[0] == 0
+
+
+def test_covisibility_in_a_supplied_numbering_is_that_of_the_renumbered_scene():
+    """What a sharded caller hands to srk_ba_set_covisibility after srk_ba_set_frame_order: min_cv of the scene as the
+    library stores it."""
+    from surikatoko_amd.ba import covisibility, frame_order
+    sc = sa.generate_scene(BAND)
+    shuffled = sa.renumber_frames(sc, np.random.RandomState(4).permutation(sc.M))
+    order = frame_order(shuffled)
+    assert order is not None and frame_order(sc) is None
+    renumbered = sa.renumber_frames(shuffled, order)
+    assert np.array_equal(covisibility(shuffled, order), covisibility(renumbered))
+    mc = covisibility(shuffled, order)
+    assert np.all(mc <= np.arange(sc.M)) and (np.arange(sc.M) - mc).max() <= BAND.vis_window + 1
