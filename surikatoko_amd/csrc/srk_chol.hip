@@ -110,139 +110,75 @@ __device__ __forceinline__ double fast_rcp1(double d)
 #ifndef SRK_POTRF_RCP
 #define SRK_POTRF_RCP fast_rcp1
 #endif
-// (round 3, later) G pivots per barrier pair, G = 4 or 8 (SRK_POTRF_G).  A group costs two barrier round trips plus its chain
-// of G dependent reciprocals; with eight pivots a group (two register slots of every quad, an 8 x 8 diagonal block factored
-// redundantly: 28 multipliers, 8 reciprocals) the tile pays 8 instead of 16 barrier pairs for the same 64 reciprocals.  The
-// code below is the G = 4 scheme written as loops over the group (every entry receives the same terms in the same order as
-// the hand-unrolled form it replaces: G = 4 gives the former bits).
-#ifndef SRK_POTRF_G
-#define SRK_POTRF_G 8
-#endif
-#define SRK_POTRF_LDS (3 * SRK_POTRF_G * NB) // doubles of scratch: panel P [64][G], finals Y 2 x [64][G]
-template <int G>
-__device__ __forceinline__ bool potrf64_g(double (*sD)[NB + 2], double* sPY /*[3][64][G]*/, double* sDiag /*[64]*/, double* sInv /*[64]*/)
+__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][64][4]: panel P, finals Y (two buffers)*/,
+                                        double* sDiag /*[64]*/, double* sInv /*[64]*/)
 {
-    static_assert(G == 4 || G == 8, "whole register slots");
-    constexpr int SL = G / 4;  // register slots of a group (a quad owns four consecutive columns per slot)
-    constexpr int NG = NB / G; // groups
     const int t = threadIdx.x, i = t >> 2, q = t & 3;
-    double (*sP)[G] = reinterpret_cast<double (*)[G]>(sPY);
+    double (*sP)[4] = reinterpret_cast<double (*)[4]>(sPY);
     double a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = sD[i][4 * m + q];
     // pivot health as two running scalars (a per-pivot flag would keep all 64 pivots live until the end):
     // dmin <= 0 catches non-positive pivots, 0 * d turns Inf / NaN into NaN
     double dmin = 1.0, dchk = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < SL; ++sl) sP[i][4 * sl + q] = a[sl];
+    sP[i][q] = a[0];
     lds_barrier();
-    double zp[G]; // multipliers of the previous group: its deferred updates
+    double zp0 = 0, zp1 = 0, zp2 = 0, zp3 = 0; // multipliers of the previous group: its deferred updates
 #pragma unroll
-    for (int k = 0; k < G; ++k) zp[k] = 0;
-    // (the group index must be a compile-time constant -- it selects registers of a[]: the optimizer declined to unroll a
-    // loop of this size, which sent a[] to scratch memory; a fold over an index sequence leaves it no choice)
-    auto group = [&](auto gc) __attribute__((always_inline)) {
-        constexpr int g = decltype(gc)::value;
-        double (*sY)[G] = reinterpret_cast<double (*)[G]>(sPY + G * NB * (1 + (g & 1))); // finals of this group
-        // ---- A: the G x G diagonal block of the group (rows G g .. of the panel), LDL^T with unscaled entries
-        double dd[G][G];
+    for (int g = 0; g < 16; ++g) {
+        double (*sY)[4] = reinterpret_cast<double (*)[4]>(sPY + 4 * NB * (1 + (g & 1)));      // finals of this group
+        // ---- A: the 4 x 4 diagonal block of the group (rows 4g .. 4g+3 of the panel), LDL^T with unscaled entries
+        const double2* Dp = reinterpret_cast<const double2*>(&sP[4 * g][0]);
+        const double2 d0 = Dp[0], d1 = Dp[2], d2a = Dp[4], d2b = Dp[5], d3a = Dp[6], d3b = Dp[7];
+        // ---- the previous group's rank-4 update of the slots behind this one (deferred: independent of the chain below)
+        if (g > 0) {
+            double (*sYp)[4] = reinterpret_cast<double (*)[4]>(sPY + 4 * NB * (1 + ((g - 1) & 1)));
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const double2* Dp = reinterpret_cast<const double2*>(&sP[G * g + k][0]);
-#pragma unroll
-            for (int j2 = 0; j2 < (k + 2) / 2; ++j2) {
-                const double2 v = Dp[j2];
-                dd[k][2 * j2] = v.x;
-                dd[k][2 * j2 + 1] = v.y;
-            }
-        }
-        // ---- the previous group's rank-G update of the slots behind this group's (deferred: independent of the chain below)
-        if constexpr (g > 0) {
-            double (*sYp)[G] = reinterpret_cast<double (*)[G]>(sPY + G * NB * (1 + ((g - 1) & 1)));
-#pragma unroll
-            for (int m = SL * (g + 1); m < 16; ++m) {
+            for (int m = g + 1; m < 16; ++m) {
                 const double2* yp = reinterpret_cast<const double2*>(&sYp[4 * m + q][0]);
-                double acc = a[m];
-#pragma unroll
-                for (int k2 = 0; k2 < G / 2; ++k2) {
-                    const double2 yv = yp[k2];
-                    acc = fma(-zp[2 * k2], yv.x, acc);
-                    acc = fma(-zp[2 * k2 + 1], yv.y, acc);
-                }
-                a[m] = acc;
+                const double2 y01 = yp[0], y23 = yp[1];
+                a[m] = fma(-zp3, y23.y, fma(-zp2, y23.x, fma(-zp1, y01.y, fma(-zp0, y01.x, a[m]))));
             }
         }
-        double u[G][G], r[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            double l[G];
-#pragma unroll
-            for (int j = 0; j < k; ++j) {
-                double acc = dd[k][j];
-#pragma unroll
-                for (int jj = 0; jj < j; ++jj) acc = fma(-l[jj], u[j][jj], acc);
-                u[k][j] = acc;
-                l[j] = acc * r[j];
-            }
-            double acc = dd[k][k];
-#pragma unroll
-            for (int jj = 0; jj < k; ++jj) acc = fma(-l[jj], u[k][jj], acc);
-            u[k][k] = acc;
-            r[k] = SRK_POTRF_RCP(acc);
-            dmin = fmin(dmin, acc);
-            dchk = fma(0.0, acc, dchk);
-        }
+        const double u00 = d0.x;
+        const double r0 = SRK_POTRF_RCP(u00);
+        const double u10 = d1.x, u20 = d2a.x, u30 = d3a.x;
+        const double l10 = u10 * r0, l20 = u20 * r0, l30 = u30 * r0;
+        const double u11 = fma(-l10, u10, d1.y);
+        const double r1 = SRK_POTRF_RCP(u11);
+        const double u21 = fma(-l20, u10, d2a.y), u31 = fma(-l30, u10, d3a.y);
+        const double l21 = u21 * r1, l31 = u31 * r1;
+        const double u22 = fma(-l21, u21, fma(-l20, u20, d2b.x));
+        const double r2 = SRK_POTRF_RCP(u22);
+        const double u32 = fma(-l31, u21, fma(-l30, u20, d3b.x));
+        const double l32 = u32 * r2;
+        const double u33 = fma(-l32, u32, fma(-l31, u31, fma(-l30, u30, d3b.y)));
+        const double r3 = SRK_POTRF_RCP(u33);
+        dmin = fmin(fmin(dmin, u00), fmin(u11, fmin(u22, u33)));
+        dchk = fma(0.0, u00, fma(0.0, u11, fma(0.0, u22, fma(0.0, u33, dchk))));
         // ---- B: this row against the factor.  y_k = p_k - sum_{k' < k} (y_k' / d_k') u_kk'
-        double y[G], z[G];
-#pragma unroll
-        for (int sl = 0; sl < SL; ++sl) {
-            y[4 * sl + 0] = quad_bcast<0>(a[SL * g + sl]);
-            y[4 * sl + 1] = quad_bcast<1>(a[SL * g + sl]);
-            y[4 * sl + 2] = quad_bcast<2>(a[SL * g + sl]);
-            y[4 * sl + 3] = quad_bcast<3>(a[SL * g + sl]);
+        const double p0 = quad_bcast<0>(a[g]), p1 = quad_bcast<1>(a[g]), p2 = quad_bcast<2>(a[g]), p3 = quad_bcast<3>(a[g]);
+        const double y0 = p0, z0 = y0 * r0;
+        const double y1 = fma(-z0, u10, p1), z1 = y1 * r1;
+        const double y2 = fma(-z1, u21, fma(-z0, u20, p2)), z2 = y2 * r2;
+        const double y3 = fma(-z2, u32, fma(-z1, u31, fma(-z0, u30, p3))), z3 = y3 * r3;
+        {
+            const double y01 = (q & 1) ? y1 : y0, y23 = (q & 1) ? y3 : y2;
+            a[g] = (q & 2) ? y23 : y01; // final (unscaled) entry of column 4g + q
         }
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            double acc = y[k];
-#pragma unroll
-            for (int kk = 0; kk < k; ++kk) acc = fma(-z[kk], u[k][kk], acc);
-            y[k] = acc;
-            z[k] = acc * r[k];
-        }
-#pragma unroll
-        for (int sl = 0; sl < SL; ++sl) {
-            // (values, not array elements, go into the selects: the optimizer otherwise turns "select of two elements" into a
-            // load from y[] in scratch memory at a lane-dependent index)
-            double ya = y[4 * sl], yb = y[4 * sl + 1], yc = y[4 * sl + 2], yd = y[4 * sl + 3];
-            asm volatile("" : "+v"(ya), "+v"(yb), "+v"(yc), "+v"(yd));
-            const double y01 = (q & 1) ? yb : ya, y23 = (q & 1) ? yd : yc;
-            a[SL * g + sl] = (q & 2) ? y23 : y01; // final (unscaled) entry of column G g + 4 sl + q
-        }
-        if constexpr (g < NG - 1) {
-#pragma unroll
-        for (int sl = 0; sl < SL; ++sl) sY[i][4 * sl + q] = a[SL * g + sl];
+        if (g == 15) break;
+        sY[i][q] = a[g];
         lds_barrier();
-        // the next group's slots: update, publish, barrier -- the remaining slots follow behind that barrier (above)
-#pragma unroll
-        for (int sl = 0; sl < SL; ++sl) {
-            const int m = SL * (g + 1) + sl;
-            const double2* yp = reinterpret_cast<const double2*>(&sY[4 * m + q][0]);
-            double acc = a[m];
-#pragma unroll
-            for (int k2 = 0; k2 < G / 2; ++k2) {
-                const double2 yv = yp[k2];
-                acc = fma(-z[2 * k2], yv.x, acc);
-                acc = fma(-z[2 * k2 + 1], yv.y, acc);
-            }
-            a[m] = acc;
-            sP[i][4 * sl + q] = acc;
+        // the next group's slot: update, publish, barrier -- the remaining slots follow behind that barrier (above)
+        {
+            const double2* yp = reinterpret_cast<const double2*>(&sY[4 * (g + 1) + q][0]);
+            const double2 y01 = yp[0], y23 = yp[1];
+            a[g + 1] = fma(-z3, y23.y, fma(-z2, y23.x, fma(-z1, y01.y, fma(-z0, y01.x, a[g + 1]))));
+            sP[i][q] = a[g + 1];
         }
-#pragma unroll
-        for (int k = 0; k < G; ++k) zp[k] = z[k];
+        zp0 = z0; zp1 = z1; zp2 = z2; zp3 = z3;
         lds_barrier(); // panel of group g + 1 is complete
-        }
-    };
-    [&]<int... Gs>(std::integer_sequence<int, Gs...>) { (group(std::integral_constant<int, Gs>{}), ...); }(std::make_integer_sequence<int, NG>{});
+    }
     // the owner of a diagonal entry holds its pivot d_i
 #pragma unroll
     for (int m = 0; m < 16; ++m)
@@ -263,10 +199,6 @@ __device__ __forceinline__ bool potrf64_g(double (*sD)[NB + 2], double* sPY /*[3
     if (t < NB) sInv[t] = fast_rcp(sD[t][t]);
     lds_barrier();
     return !(dmin > 0.0) || (dchk != 0.0);
-}
-__device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY, double* sDiag, double* sInv)
-{
-    return potrf64_g<SRK_POTRF_G>(sD, sPY, sDiag, sInv);
 }
 
 // ---------------------------------------------------------------- batched launches
@@ -416,7 +348,7 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
     __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
     __shared__ double sZ[NB][NB + 1]; // inverse workgroup only
     __shared__ double sT[32][33];
-    __shared__ __attribute__((aligned(16))) double sCol[SRK_POTRF_LDS]; // potrf64: panel [64][G] + finals 2 x [64][G]
+    __shared__ __attribute__((aligned(16))) double sCol[12 * NB]; // potrf64: panel [64][4] + finals 2 x [64][4]
     __shared__ double sDiag[NB];
     __shared__ double sInv[NB];
     __shared__ double sy[NB];
@@ -732,12 +664,12 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
     // One region for the role-specific scratch: the inverse role's sT, or the other roles' potrf panel / finals, sInv and sy.
     // (Round 3: with separate arrays the kernel held 83.7 KB of LDS -- 3 KB too much for TWO workgroups on a CU's 160 KB, so
     // the ~416 workgroups of a speculative pair's two solves took turns on the 256 CUs instead of running side by side.)
-    __shared__ __attribute__((aligned(16))) double sU[32 * 33 > SRK_POTRF_LDS + 2 * NB ? 32 * 33 : SRK_POTRF_LDS + 2 * NB];
+    __shared__ __attribute__((aligned(16))) double sU[32 * 33 > 14 * NB ? 32 * 33 : 14 * NB];
     __shared__ double sDiag[NB];
     double (*sT)[33] = reinterpret_cast<double (*)[33]>(sU);   // inverse role only
-    double* sCol = sU;                                         // [SRK_POTRF_LDS] potrf64: panel + two buffers of finals
-    double* sInv = sU + SRK_POTRF_LDS;                         // [NB]
-    double* sy = sU + SRK_POTRF_LDS + NB;                      // [NB]
+    double* sCol = sU;                                         // [12 NB] potrf64: panel + two buffers of finals
+    double* sInv = sU + 12 * NB;                               // [NB]
+    double* sy = sU + 13 * NB;                                 // [NB]
     static_assert(sizeof(double) * NB * (NB + 2) >= sizeof(double) * NB * (NB + 1), "sZ fits sA");
     static_assert(2 * (2 * sizeof(double) * NB * (NB + 2) + sizeof(sU) + sizeof(double) * NB) <= 160 * 1024, "two workgroups per CU");
     if (role == 4) { // ---- inverses of the diagonal tiles, as they are published
