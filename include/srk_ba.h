@@ -251,9 +251,13 @@ double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates o
  * each 256-column outer step of the blocked Cholesky is ONE launch whose workgroups hand factored tiles to one another
  * (bounded spins; a timed-out hand-off makes the LM loop repeat that attempt with the unfused sequence and stay there),
  * 0 = one launch per 64-column panel and per rank-64 update.  Both give bit-identical results.  Takes effect at once.
- * srk_ba_solver_sync_timeouts: how many solves had to be repeated (0 in every run so far). */
+ * srk_ba_solver_sync_timeouts: how many solves had to be repeated (0 in every run so far).  A timeout is a scheduling event
+ * (another process on the GPU, a debugger), so the unfused sequence is kept only for the rest of that call: the next upload /
+ * optimise call uses the fused step again -- until the handle has seen three timeouts since the last
+ * srk_ba_set_solver_fusion(h, 1); then the unfused sequence stays.  srk_ba_solver_fusion: 1 = fused right now, 0 = unfused. */
 int srk_ba_set_solver_fusion(srk_ba*, int on);
 int64_t srk_ba_solver_sync_timeouts(srk_ba*);
+int srk_ba_solver_fusion(srk_ba*);
 
 /* Speculative attempts (default on; takes effect at the next upload): with the instrumentation off
  * (srk_ba_set_profile 0, the default) the LM loop runs the next damping factor on a second stream beside the current

@@ -318,6 +318,10 @@ class BundleAdjustmentKanatani:
         """Outer steps of the blocked Cholesky as one launch each (default) or as the panel / update launch sequence."""
         self._raise(self._lib.srk_ba_set_solver_fusion(C.c_void_p(self._h), C.c_int(int(bool(on)))))
 
+    def solver_fusion(self):
+        """True while the fused outer step is in use (False after a hand-off timeout, until the next upload / optimise call)"""
+        return bool(self._lib.srk_ba_solver_fusion(C.c_void_p(self._h)))
+
     def solver_sync_timeouts(self):
         self._lib.srk_ba_solver_sync_timeouts.restype = C.c_int64
         return int(self._lib.srk_ba_solver_sync_timeouts(C.c_void_p(self._h)))

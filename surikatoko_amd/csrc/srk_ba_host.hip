@@ -35,6 +35,7 @@ struct DevBuf {
 
 } // namespace
 
+#define SRK_FUSION_RETRIES 3
 #define SRK_SLOTS 3 // attempt slots: two on one GPU (speculative pairs), up to three with several ranks (one damping factor each)
 struct srk_ba {
     int device = 0;
@@ -145,6 +146,11 @@ struct srk_ba {
     bool store_f32 = false;  // opt-in: the point-frame blocks W are STORED as float (next upload); arithmetic stays fp64
     int profile_level = 0; // 0 = no events, 1 = phase events (report.ms_*), 2 = + event pairs around the MFMA updates
     bool chol_fused = true; // the solve's outer steps as one launch each (k_step256); srk_ba_set_solver_fusion
+    // what the caller asked for.  A hand-off timeout switches chol_fused off for the rest of that call; the next upload /
+    // optimise call switches it back on (a timeout is a scheduling event: another process on the GPU, a debugger) until the
+    // handle has seen SRK_FUSION_RETRIES of them -- then the unfused sequence stays, and srk_ba_solver_sync_timeouts says so.
+    bool chol_fused_wanted = true;
+    int fusion_rearms_left = 3; // SRK_FUSION_RETRIES
     int64_t sync_timeouts = 0; // solves repeated with the unfused kernels after a hand-off timed out
     int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
@@ -264,7 +270,7 @@ srk_ba* srk_ba_create(int device_id)
         return nullptr;
     }
     h->main_stream = h->stream;
-    if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = e[0] != '0'; // development: the unfused launch sequence
+    if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = h->chol_fused_wanted = e[0] != '0'; // development: the unfused launch sequence
     if (const char* e = getenv("SRK_MULTI_SPECULATION")) h->spec_multi = e[0] != '0';
     if (const char* e = getenv("SRK_MULTI_SCHEDULE")) {
         h->dp_schedule = std::strcmp(e, "allreduce") != 0;
@@ -870,6 +876,7 @@ static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr
     return mode > 0 ? differs : 10 * bw_new <= 7 * bw_nat;
 }
 
+static void rearm_fusion(srk_ba* h);
 extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
                                    const double* cam_R_in, const double* cam_T_in, const double* K_in, int shared_k,
                                    const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
@@ -877,6 +884,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
 {
     int rc = validate_scene(h, f0, N, pts_in, M, cam_R_in, cam_T_in, K_in, row_ptr, obs_frame, obs_uv);
     if (rc != SRK_OK) return rc;
+    rearm_fusion(h);
     HIPCHK(h, hipSetDevice(h->device));
     h->have_scene = false;
     h->seen_global = -1;
@@ -1354,6 +1362,16 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     return SRK_OK;
 }
 
+// entry of an upload / optimise call: the fused outer steps again after an earlier call's hand-off timeout (see chol_fused_wanted).
+// Every rank of a sharded run counts the same timeouts (the status words are exchanged), so all re-arm together.
+static void rearm_fusion(srk_ba* h)
+{
+    if (!h->chol_fused_wanted || h->chol_fused || h->fusion_rearms_left <= 0) return;
+    --h->fusion_rearms_left;
+    h->chol_fused = true;
+    for (auto& a : h->att) a.sync.fused = true;
+}
+
 // after a failed solve: every slot's system and zero-initialised plan buffers back to zeros (see srk_ba::poisoned)
 static int clear_poison(srk_ba* h)
 {
@@ -1769,6 +1787,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     const SrkDims& d = h->d;
     auto t_begin = std::chrono::steady_clock::now();
     rep->world_scale = h->nrm.world_scale;
+    rearm_fusion(h);
     {
         int rcp = clear_poison(h);
         if (rcp != SRK_OK) return rcp;
@@ -2743,11 +2762,13 @@ double srk_ba_solve_mfma_flops(srk_ba* h)
 int srk_ba_set_solver_fusion(srk_ba* h, int on)
 {
     if (!h || (on != 0 && on != 1)) return SRK_E_ARGS;
-    h->chol_fused = on != 0;
+    h->chol_fused = h->chol_fused_wanted = on != 0;
+    h->fusion_rearms_left = SRK_FUSION_RETRIES; // an explicit request renews the budget
     for (auto& a : h->att) a.sync.fused = h->chol_fused;
     return SRK_OK;
 }
 int64_t srk_ba_solver_sync_timeouts(srk_ba* h) { return h ? h->sync_timeouts : -1; }
+int srk_ba_solver_fusion(srk_ba* h) { return h ? (h->chol_fused ? 1 : 0) : -1; }
 
 int srk_ba_set_speculation(srk_ba* h, int on)
 {

@@ -1211,10 +1211,25 @@ def test_a_lost_hand_off_times_out_and_the_attempt_is_repeated_with_the_panel_se
         s2 = sc.copy()
         gpu.ComputeInplace(spec.f0, s2, None, 3)
         assert gpu.solver_sync_timeouts() == before + 1
+        assert not gpu.solver_fusion()    # unfused for the rest of that call ...
         assert (gpu.report.iterations, gpu.report.attempts) == ref[:2]
         assert gpu.report.err_final == pytest.approx(ref[2], rel=1e-9)
         assert np.abs(s2.points - s1.points).max() < 1e-9
         assert np.abs(s2.cam_T - s1.cam_T).max() < 1e-9
+        # ... and fused again from the next call on (a timeout is a scheduling event, not a property of the handle); after
+        # three timeouts the unfused sequence stays until the caller asks for fusion again
+        s3 = sc.copy()
+        gpu.ComputeInplace(spec.f0, s3, None, 3)
+        assert gpu.solver_fusion() and gpu.solver_sync_timeouts() == before + 1
+        assert np.abs(s3.points - s1.points).max() < 1e-9
+        for k in range(2, 5):
+            sa.lib().srk_dbg_step_fault(1)
+            gpu.ComputeInplace(spec.f0, sc.copy(), None, 2)
+            assert gpu.solver_sync_timeouts() == before + min(k, 4)
+        gpu.ComputeInplace(spec.f0, sc.copy(), None, 2)
+        assert not gpu.solver_fusion() and gpu.solver_sync_timeouts() == before + 4
+        gpu.set_solver_fusion(1)
+        assert gpu.solver_fusion()
     finally:
         sa.lib().srk_dbg_step_fault(0)
         gpu.set_solver_fusion(1)
