@@ -2132,6 +2132,10 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             return 0;
         };
         const int pat = __builtin_amdgcn_readfirstlane(100 * pattern(0) + pattern(4));
+        // the three waves that are not 2 x 4 blocks (one each on SIMDs 1 .. 3) read more operands per MFMA and wait before every
+        // one of them: alone at the end of a double round they would crawl -- they run ahead of the block waves instead
+        // (Schur phase 402.5 -> 397.5 us, six interleaved runs; priority 1, 2 or 3, helpers at 2 or 3: the same)
+        if (runs && !blk) __builtin_amdgcn_s_setprio(1);
         auto rounds = [&](auto p0, auto p1) {
             if (!ragged) { // uniform runs: double rounds of Z^T Z (see the helpers), round u in buffer u % 6
                 for (int r = 0; r < R; r += 2) {
