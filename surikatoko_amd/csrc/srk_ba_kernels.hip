@@ -2140,7 +2140,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (!ragged) { // uniform runs: double rounds of Z^T Z (see the helpers), round u in buffer u % 6
                 for (int r = 0; r < R; r += 2) {
                     const double* bw = sBuf + (r % 6) * WB;
-#ifdef SRK_SCH_NOACC
+#if defined(SRK_SCH_NOACC) || defined(SRK_MM_NO_ROWWAVES) // (ablations, wrong results; NO_ROWWAVES: the three non-block waves multiply nothing)
                     if (d.N < 0)
 #endif
                     {
