@@ -1571,14 +1571,69 @@ __device__ __forceinline__ void schur_mm_steps_blk(srk_double4 (&acc)[SRK_MM_SLO
 // nt = 13 (20 frames): the 91 tiles of the lower triangle over the 12 multiplying waves.  Nine waves take a 2 x 4 block
 // (two tile rows, four tile columns; where the block reaches over the diagonal that tile is computed and not flushed),
 // wave 9 the first eight tiles of the last row, waves 10 and 11 what is left.  {ti, tj} per slot, ti < 0: idle slot.
+#define SRK_MM_TILES13_ROWS \
+    { { 12, 0 }, { 12, 1 }, { 12, 2 }, { 12, 3 }, { 12, 4 }, { 12, 5 }, { 12, 6 }, { 12, 7 } }, \
+    { { 12, 8 }, { 12, 9 }, { 12, 10 }, { 12, 11 }, { 12, 12 }, { 8, 8 }, { 9, 8 }, { 9, 9 } }, \
+    { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { -1, 0 }, { -1, 0 } }
 __device__ const signed char srk_mm_tiles13[SRK_MM_CW][SRK_MM_SLOTS][2] = {
 #define SRK_BLK(r, c) { { r, c }, { r, c + 1 }, { r, c + 2 }, { r, c + 3 }, { r + 1, c }, { r + 1, c + 1 }, { r + 1, c + 2 }, { r + 1, c + 3 } }
     SRK_BLK(10, 0), SRK_BLK(10, 4), SRK_BLK(10, 8), SRK_BLK(8, 0), SRK_BLK(8, 4), SRK_BLK(6, 0), SRK_BLK(6, 4), SRK_BLK(4, 0), SRK_BLK(2, 0),
 #undef SRK_BLK
-    { { 12, 0 }, { 12, 1 }, { 12, 2 }, { 12, 3 }, { 12, 4 }, { 12, 5 }, { 12, 6 }, { 12, 7 } },
-    { { 12, 8 }, { 12, 9 }, { 12, 10 }, { 12, 11 }, { 12, 12 }, { 8, 8 }, { 9, 8 }, { 9, 9 } },
-    { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { -1, 0 }, { -1, 0 } },
+    SRK_MM_TILES13_ROWS,
 };
+// The three waves that are not blocks (9, 10, 11), uniform runs: their tile lists are known at compile time, and in the SYRK
+// form the A operand of tile row t and the B operand of tile column t are the SAME 16 columns of Z -- one LDS read per
+// DISTINCT tile index of the wave per K step (wave 9: 9 for its 8 MFMAs, wave 10: 5 for 8, wave 11: 4 for 6; the pattern
+// code they ran before: 9-10, 13, 14 and a wait before every MFMA), operand sets per K step like the block waves, idle
+// slots skipped.  Same products in the same order per accumulator: the sums keep their bits.
+struct SrkRowWave {
+    signed char t[16]; // distinct tile indices
+    signed char ia[SRK_MM_SLOTS], ib[SRK_MM_SLOTS]; // slot -> operand (index into t), -1: idle slot
+    int nt;
+};
+constexpr SrkRowWave srk_row_wave(int w)
+{
+    constexpr signed char tab[3][SRK_MM_SLOTS][2] = { SRK_MM_TILES13_ROWS };
+    SrkRowWave o{};
+    o.nt = 0;
+    for (int s = 0; s < SRK_MM_SLOTS; ++s) {
+        o.ia[s] = o.ib[s] = -1;
+        if (tab[w][s][0] < 0) continue;
+        for (int side = 0; side < 2; ++side) {
+            const signed char v = tab[w][s][side];
+            int k = 0;
+            while (k < o.nt && o.t[k] != v) ++k;
+            if (k == o.nt) o.t[o.nt++] = v;
+            (side == 0 ? o.ia[s] : o.ib[s]) = (signed char)k;
+        }
+    }
+    return o;
+}
+template <int W>
+__device__ __forceinline__ void schur_mm_steps_row(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, int lbase)
+{
+    constexpr SrkRowWave RW = srk_row_wave(W);
+    struct Ops { double v[RW.nt]; };
+    auto load = [&](Ops& o, int ks) {
+        int lb = lbase;
+        asm volatile("" : "+v"(lb));
+        const int ko = ks * 4 * SRK_MM_LDW;
+#pragma unroll
+        for (int k = 0; k < RW.nt; ++k) o.v[k] = bw[ko + lb + 16 * RW.t[k]];
+    };
+    auto mac = [&](const Ops& o) {
+#pragma unroll
+        for (int s = 0; s < SRK_MM_SLOTS; ++s)
+            if constexpr (true) {
+                if (RW.ia[s] >= 0) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.v[RW.ia[s] < 0 ? 0 : RW.ia[s]], o.v[RW.ib[s] < 0 ? 0 : RW.ib[s]], acc[s], 0, 0, 0);
+            }
+    };
+    Ops o0, o1;
+    load(o0, 0);
+    load(o1, 1); mac(o0);
+    load(o0, 2); mac(o1);
+    mac(o0);
+}
 // KIND 0: every run of the scene is uniform (all its landmarks see the same frames: the bench scenes) -- SYRK form, double
 // rounds; KIND 1: the scene has runs over the UNION of different frame lists -- W + Y form with masks, which serves a uniform
 // run as well (full masks), so a scene with both kinds (the dino stand-in) is ONE launch, not two latency-bound ones.  Two
@@ -2170,7 +2225,26 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                 MM_ACC(0, 7, tacc);
             }
         };
-        if (blk) {
+        auto rounds_row = [&](auto wc) { // waves 9 .. 11 of the full-size grid, uniform runs (schur_mm_steps_row)
+            for (int r = 0; r < R; r += 2) {
+                const double* bw = sBuf + (r % 6) * WB;
+#if defined(SRK_SCH_NOACC) || defined(SRK_MM_NO_ROWWAVES)
+                if (d.N < 0)
+#endif
+                {
+                    schur_mm_steps_row<decltype(wc)::value>(acc, bw, lbase);
+                    if (r + 1 < R) schur_mm_steps_row<decltype(wc)::value>(acc, bw + WB, lbase);
+                }
+                MM_ACC(0, 6, tacc);
+                lds_barrier();
+                MM_ACC(0, 7, tacc);
+            }
+        };
+        if (runs && !blk) {
+            if (wvu == 9) rounds_row(std::integral_constant<int, 0>{});
+            else if (wvu == 10) rounds_row(std::integral_constant<int, 1>{});
+            else rounds_row(std::integral_constant<int, 2>{});
+        } else if (blk) {
             for (int r = 0; r < R; r += 2) { // uniform runs: double rounds (see the helpers), round u in buffer u % 6
                 const double* bw = sBuf + (r % 6) * WB; // Z^T Z: both operands read the one staged array
 #ifdef SRK_SCH_NOACC
