@@ -1538,7 +1538,8 @@ __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS],
 // tiles 4 .. 7: row ta[4], the same columns): two A and four B operands serve the eight MFMAs of a K step -- 6 LDS reads
 // instead of 16 -- and the operand sets are per K step (the next one's reads in flight under eight MFMAs)
 __device__ __forceinline__ void schur_mm_steps_blk(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, const double* by,
-                                                   const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int lbase)
+                                                   const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int lbase,
+                                                   bool skip3 /* wave-uniform: tile 3 lies above the diagonal, never flushed */)
 {
     struct Ops { double alo, ahi, b[4]; };
     auto load = [&](Ops& o, int ks) {
@@ -1552,7 +1553,8 @@ __device__ __forceinline__ void schur_mm_steps_blk(srk_double4 (&acc)[SRK_MM_SLO
     };
     auto mac = [&](const Ops& o) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo, o.b[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo, o.b[j], acc[j], 0, 0, 0);
+        if (!skip3) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.alo, o.b[3], acc[3], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.ahi, o.b[j], acc[4 + j], 0, 0, 0);
     };
@@ -1572,9 +1574,9 @@ __device__ __forceinline__ void schur_mm_steps_blk(srk_double4 (&acc)[SRK_MM_SLO
 // (two tile rows, four tile columns; where the block reaches over the diagonal that tile is computed and not flushed),
 // wave 9 the first eight tiles of the last row, waves 10 and 11 what is left.  {ti, tj} per slot, ti < 0: idle slot.
 #define SRK_MM_TILES13_ROWS \
-    { { 12, 0 }, { 12, 1 }, { 12, 2 }, { 12, 3 }, { 12, 4 }, { 12, 5 }, { 12, 6 }, { 12, 7 } }, \
+    { { 12, 0 }, { 12, 1 }, { 12, 2 }, { 12, 3 }, { 12, 4 }, { 12, 5 }, { 12, 6 }, { -1, 0 } }, \
     { { 12, 8 }, { 12, 9 }, { 12, 10 }, { 12, 11 }, { 12, 12 }, { 8, 8 }, { 9, 8 }, { 9, 9 } }, \
-    { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { -1, 0 }, { -1, 0 } }
+    { { 4, 4 }, { 5, 4 }, { 5, 5 }, { 0, 0 }, { 1, 0 }, { 1, 1 }, { 12, 7 }, { -1, 0 } }
 __device__ const signed char srk_mm_tiles13[SRK_MM_CW][SRK_MM_SLOTS][2] = {
 #define SRK_BLK(r, c) { { r, c }, { r, c + 1 }, { r, c + 2 }, { r, c + 3 }, { r + 1, c }, { r + 1, c + 1 }, { r + 1, c + 2 }, { r + 1, c + 3 } }
     SRK_BLK(10, 0), SRK_BLK(10, 4), SRK_BLK(10, 8), SRK_BLK(8, 0), SRK_BLK(8, 4), SRK_BLK(6, 0), SRK_BLK(6, 4), SRK_BLK(4, 0), SRK_BLK(2, 0),
@@ -2245,14 +2247,18 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             else if (wvu == 10) rounds_row(std::integral_constant<int, 1>{});
             else rounds_row(std::integral_constant<int, 2>{});
         } else if (blk) {
+            // a block that reaches over the diagonal (rows r, r + 1, columns r - 2 .. r + 1): its tile 3 = (r, r + 1) is never
+            // flushed -- not multiplied either (7 MFMAs a K step: with the table's tile counts the SIMDs hold 23, 23, 22, 23
+            // MFMAs a K step instead of 24 each)
+            const bool skip3 = __builtin_amdgcn_readfirstlane((int)(tb[3] > ta[3])) != 0;
             for (int r = 0; r < R; r += 2) { // uniform runs: double rounds (see the helpers), round u in buffer u % 6
                 const double* bw = sBuf + (r % 6) * WB; // Z^T Z: both operands read the one staged array
 #ifdef SRK_SCH_NOACC
                 if (d.N < 0)
 #endif
                 {
-                    schur_mm_steps_blk(acc, bw, bw, ta, tb, lbase);
-                    if (r + 1 < R) schur_mm_steps_blk(acc, bw + WB, bw + WB, ta, tb, lbase);
+                    schur_mm_steps_blk(acc, bw, bw, ta, tb, lbase, skip3);
+                    if (r + 1 < R) schur_mm_steps_blk(acc, bw + WB, bw + WB, ta, tb, lbase, skip3);
                 }
                 MM_ACC(0, 6, tacc);
 #ifndef SRK_MM_NO_ROUND_BARRIER
