@@ -1662,6 +1662,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
     __shared__ double sRhs[SRK_WS_NF * 10];
     __shared__ int32_t sVar[SRK_WS_NF * 10]; // row / column of S of the sum's row / column e; -1: a gauge-fixed variable
+    // KIND 1, fp64 factors: first observation (relative to the run's) and frame-slot mask of every landmark of the run
+    __shared__ int32_t sOff[KIND == 1 ? SRK_GRP_MAXPTS : 1];
+    __shared__ uint32_t sMask[KIND == 1 ? SRK_GRP_MAXPTS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef SRK_MM_STAMPS
     if (tid == 64 * SRK_MM_CW && blockIdx.x < 2048) for (int k = 10; k < 16; ++k) g_mm_stamps[blockIdx.x][k] = 0;
@@ -1681,7 +1684,10 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
     const int nfu = grp_nf[blockIdx.x];
-    constexpr bool ragged = KIND == 1;
+    // fp64 factor storage: both kinds take the SYRK form (`masked`: KIND 1, a cell (landmark, frame slot) the landmark does not
+    // see is staged as zeros); `ragged` = the W + Y form with masks, left for the opt-in float storage of W
+    constexpr bool masked = KIND == 1 && WStore<WT>::factored;
+    constexpr bool ragged = KIND == 1 && !WStore<WT>::factored;
     if (KIND == 0 && nfu < 0) return; // (never launched on such a scene)
     const int nf = nfu < 0 ? -nfu : nfu;
     if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
@@ -1695,7 +1701,23 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int64_t o0 = row_ptr[p0];
     // LDS column of observation (staged landmark pl, frame slot a), W row k = 10 m + r:  (3 pl + m) LDW + 10 a + r
     // rounds 0 and 1 are staged by the whole workgroup, their loads in flight together with the 3x3 blocks' below
-    constexpr bool rows01 = KIND == 0 && WStore<WT>::factored; // rounds 0 and 1 staged as Z rows here (below)
+    constexpr bool rows01 = WStore<WT>::factored; // rounds 0 and 1 staged as Z rows here (below)
+    // (masked) the cell (landmark pl of round rd, frame slot a): which observation, if any.  Runs over the UNION of their
+    // landmarks' frame lists: a landmark's observations are its mask's set bits in slot order.
+    auto cell_obs = [&](int pidx, int a, bool& seen) -> unsigned {
+        seen = false;
+        if (pidx >= np) return 0u;
+        const uint32_t mk = sMask[pidx];
+        seen = (mk >> a) & 1u;
+        return (unsigned)(o0 + sOff[pidx] + __builtin_popcount(mk & ((1u << a) - 1u)));
+    };
+    if constexpr (masked) {
+        if (tid < np) {
+            sOff[tid] = (int32_t)(row_ptr[p0 + tid] - o0);
+            sMask[tid] = pt_mask[p0 + tid];
+        }
+        __syncthreads();
+    }
     if constexpr (rows01) {
         // fp64 factors, uniform runs: thread (rd, sm, sq) of the first 2 * 3 * QMAX takes row sm of observation sq of round
         // rd, like the helpers' stage_round2 -- its 21 factor loads are in flight together with the 3x3 blocks' loads, Z leaves
@@ -1706,10 +1728,17 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int rd = tid / (3 * QMAX), rem = tid - rd * (3 * QMAX);
         const int sm = rem / QMAX, sq = rem - sm * QMAX;
         const int oa = rd ? o1 : 0, nq = rd < 2 ? (rd ? o2 - o1 : o1) : 0;
-        const bool row_on = sq < nq;
+        bool row_on = sq < nq;
+        bool cell = false; // (masked) a cell of the round's (landmark, slot) grid: written in any case, zeros when not seen
+        unsigned voff = (unsigned)(o0 + oa + sq);
+        if constexpr (masked) {
+            const int pl = sq / nf, a = sq - pl * nf;
+            cell = rd < 2 && pl < PB;
+            row_on = false;
+            if (cell) voff = cell_obs(rd * PB + pl, a, row_on);
+        }
         double f[SRK_WF_PLANES];
         if (row_on) {
-            const unsigned voff = (unsigned)(o0 + oa + sq);
 #pragma unroll
             for (int k = 0; k < SRK_WF_PLANES; ++k) f[k] = (W + (int64_t)k * d.Os)[voff];
         }
@@ -1742,6 +1771,11 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
 #pragma unroll
             for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], z[i] * hm);
+        } else if (masked && cell) {
+            const int pl = sq / nf, a = sq - pl * nf;
+            double2* wp = reinterpret_cast<double2*>(sBuf + rd * WB + (3 * pl + sm) * LDW + 10 * a);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wp[i] = make_double2(0.0, 0.0);
         }
     } else {
         const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
@@ -1966,14 +2000,22 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int pl3 = sq3 / nf, a3 = sq3 - pl3 * nf;
         const int dst3 = (3 * pl3 + sm3) * LDW + 10 * a3;
         double f3[SRK_WF_PLANES], racc3[10];
+        bool cell3 = false; // (masked) this lane owns a cell of the round in flight
 #pragma unroll
         for (int i = 0; i < 10; ++i) racc3[i] = 0;
         auto load_round2 = [&](int r) {
             const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
             if constexpr (WStore<WT>::factored) {
-                nq2 = sm3 < 3 ? rb - ra : 0;
+                unsigned voff = (unsigned)(o0 + ra + sq3);
+                if constexpr (masked) { // the cell (landmark pl3 of the round, slot a3): seen -> its observation, else zeros
+                    cell3 = sm3 < 3 && pl3 < PB;
+                    bool seen = false;
+                    if (cell3) voff = cell_obs(r * PB + pl3, a3, seen);
+                    nq2 = seen ? QMAX : 0; // (sq3 < nq2  <=>  seen)
+                } else {
+                    nq2 = sm3 < 3 ? rb - ra : 0;
+                }
                 if (sq3 < nq2) {
-                    const unsigned voff = (unsigned)(o0 + ra + sq3);
 #pragma unroll
                     for (int k = 0; k < SRK_WF_PLANES; ++k) {
                         const WT* sb = W + (int64_t)k * d.Os; // wave-uniform plane base
@@ -2021,6 +2063,10 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                     for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
 #pragma unroll
                     for (int i = 0; i < 10; ++i) racc3[i] = fma(z[i], hm, racc3[i]);
+                } else if (masked && cell3) { // the landmark does not see this frame (or the round is short): a block of zeros
+                    double2* wp = reinterpret_cast<double2*>(bw + dst3);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) wp[i] = make_double2(0.0, 0.0);
                 }
             } else {
             if (q2 < nq2) {
