@@ -74,7 +74,8 @@ struct srk_ba {
     int64_t n_mm_uniform = 0, n_mm_ragged = 0; // runs the MFMA kernel takes (<= SRK_WS_NF_HOST frames), by kind
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // run-based Jacobian kernel (k_jac_runs): tasks = pieces of runs of landmarks with identical frame lists
-    DevBuf jr_first, jr_count, jr_jmin;
+    DevBuf jr_first, jr_count, jr_jmin, jr_group;
+    bool jac_runs_masked = false; // the tasks are pieces of the Schur kernel's runs over UNIONS of frame lists (ragged tracks)
     int32_t jr_tasks = 0, jr_min_nf = 64;
     bool jac_runs = false;  // the tasks are long enough to pay and every workgroup's frame window fits
     int jac_mode = -1;      // -1 = automatic, 0 = never k_jac_runs, 1 = whenever possible (srk_ba_set_jacobian_mode)
@@ -327,7 +328,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
                       &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off,
-                      &h->jr_first, &h->jr_count, &h->jr_jmin, &h->lg_item, &h->lg_np, &h->lg_nf, &h->lg_pts, &h->lg_frames,
+                      &h->jr_first, &h->jr_count, &h->jr_jmin, &h->jr_group, &h->lg_item, &h->lg_np, &h->lg_nf, &h->lg_pts, &h->lg_frames,
                       &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
@@ -1217,6 +1218,39 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             jr_jmin.push_back(lo);
         }
     }
+    // Ragged tracks: hardly two landmarks see exactly the same frames, so the runs above are too short to pay -- but the
+    // Schur kernel's runs (consecutive landmarks over the UNION of their frame lists, <= 24 frames, masks) are not.  The same
+    // kernel with a lane per (landmark, frame slot) CELL: tasks = pieces of those runs.  Needs every landmark in a run.
+    std::vector<int32_t> jr_group;
+    h->jac_runs_masked = false;
+    if (!h->jac_runs && h->jac_mode != 0 && O < (int64_t)1 << 27 && long_cand.empty() && gen_list.empty() && !grp_first.empty()) {
+        jr_first.clear();
+        jr_count.clear();
+        jr_jmin.clear();
+        for (size_t gi = 0; gi < grp_first.size(); ++gi) {
+            const int64_t nfu = std::abs(grp_nf[gi]), g = 64 / nfu, len = grp_count[gi];
+            const int64_t most = SRK_JR_TASK_PTS_MAX_HOST / g * g;
+            const int64_t pieces = std::max<int64_t>((len + most - 1) / most, (len + jr_piece_target / 2) / jr_piece_target);
+            const int64_t piece = std::max<int64_t>(g, ((len + pieces - 1) / pieces + g - 1) / g * g);
+            for (int64_t a = 0; a < len; a += piece) {
+                jr_first.push_back(grp_first[gi] + (int32_t)a);
+                jr_count.push_back((int32_t)std::min<int64_t>(piece, len - a));
+                jr_group.push_back((int32_t)gi);
+            }
+        }
+        bool ok = h->jac_mode == 1 || O / (int64_t)jr_first.size() >= 256;
+        for (size_t t0 = 0; t0 < jr_first.size() && ok; t0 += 4) {
+            int32_t lo = M, hi = -1;
+            for (size_t t = t0; t < std::min(jr_first.size(), t0 + 4); ++t) {
+                const size_t gi = (size_t)jr_group[t];
+                lo = std::min(lo, grp_frames[gi * SRK_GRP_MAXNF_HOST]);
+                hi = std::max(hi, grp_frames[gi * SRK_GRP_MAXNF_HOST + (size_t)std::abs(grp_nf[gi]) - 1]);
+            }
+            if (hi - lo >= SRK_JF_SLOTS_HOST) ok = false;
+            jr_jmin.push_back(lo);
+        }
+        h->jac_runs = h->jac_runs_masked = ok;
+    }
     h->jr_tasks = h->jac_runs ? (int32_t)jr_first.size() : 0;
 
 #define ALLOC(buf, bytes)                              \
@@ -1292,6 +1326,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         ALLOC(h->jr_first, 4 * jr_first.size());
         ALLOC(h->jr_count, 4 * jr_count.size());
         ALLOC(h->jr_jmin, 4 * jr_jmin.size());
+        if (h->jac_runs_masked) ALLOC(h->jr_group, 4 * jr_group.size());
     }
 #undef ALLOC
     hipStream_t s = h->stream;
@@ -1332,6 +1367,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         H2D(h->jr_first, jr_first.data(), 4 * jr_first.size());
         H2D(h->jr_count, jr_count.data(), 4 * jr_count.size());
         H2D(h->jr_jmin, jr_jmin.data(), 4 * jr_jmin.size());
+        if (h->jac_runs_masked) H2D(h->jr_group, jr_group.data(), 4 * jr_group.size());
     }
 #undef H2D
     for (auto& a : h->att) {
@@ -1552,7 +1588,9 @@ static int phase_derivatives(srk_ba* h)
     if (h->jac_runs) {
         srk_launch_jac_runs(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame),
                             P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg), P<double>(h->Ug), P<int32_t>(h->jr_first),
-                            P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin), h->jr_min_nf);
+                            P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin),
+                            h->jac_runs_masked ? P<int32_t>(h->jr_group) : nullptr, P<int32_t>(h->grp_nf), P<int32_t>(h->grp_frames),
+                            P<uint32_t>(h->pt_mask));
         if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
     } else if (h->jac_fused) {
         srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),

@@ -467,7 +467,12 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
 // task (neighbouring pieces written together): +5 us.
 #define SRK_JR_RSTRIDE 66 // doubles between the 9 planes of the per-wave reduction scratch (64 lanes + bank skew)
 
-template <typename WT>
+// MASKED (round 3): the task is a piece of a run over the UNION of its landmarks' frame lists (the runs of the Schur kernel:
+// grp_*, pt_mask) -- ragged feature tracks, where hardly two landmarks see exactly the same frames.  Lane (m, f) owns the CELL
+// (landmark m of the step, frame slot f of the union): the cell's observation is the landmark's first one plus the number of
+// mask bits below the slot; a cell the landmark does not see computes nothing and adds zeros to the landmark's sums.  A lane
+// still stays on one frame for the whole task.  The landmarks' first observations and masks sit in a per-wave LDS table.
+template <typename WT, bool MASKED>
 __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __restrict__ pts,
                                                      const double* __restrict__ cam,
                                                      const int64_t* __restrict__ row_ptr,
@@ -476,8 +481,12 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                                                      double* __restrict__ Vg, double* __restrict__ Ug,
                                                      const int32_t* __restrict__ task_first,
                                                      const int32_t* __restrict__ task_count, int32_t n_tasks,
-                                                     const int32_t* __restrict__ wg_jmin)
+                                                     const int32_t* __restrict__ wg_jmin,
+                                                     const int32_t* __restrict__ task_group, const int32_t* __restrict__ grp_nf,
+                                                     const int32_t* __restrict__ grp_frames, const uint32_t* __restrict__ pt_mask)
 {
+    __shared__ int32_t sTOff[MASKED ? 4 : 1][MASKED ? SRK_JR_TASK_PTS_MAX_HOST : 1];
+    __shared__ uint32_t sTMask[MASKED ? 4 : 1][MASKED ? SRK_JR_TASK_PTS_MAX_HOST : 1];
     __shared__ double sU[SRK_JF_SLOTS][SRK_UG + 1];                                  // frame blocks + frame gradients
     __shared__ __attribute__((aligned(16))) double sCam[SRK_JF_SLOTS][SRK_CAM_PACK]; // camera packs of the frame window
     __shared__ double sR[4][9 * SRK_JR_RSTRIDE];                                     // per-wave landmark reduction
@@ -498,11 +507,33 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
     if (task < n_tasks) {
         const int32_t first_pt = task_first[task], n_pts = task_count[task];
         const int64_t o_base = row_ptr[first_pt];
-        const int nf = (int)(row_ptr[first_pt + 1] - o_base);
+        int nf = (int)(row_ptr[first_pt + 1] - o_base);
+        const int32_t* fr = nullptr; // (MASKED) the run's frame set
+        if constexpr (MASKED) {
+            const int gi = task_group[task];
+            nf = grp_nf[gi] < 0 ? -grp_nf[gi] : grp_nf[gi];
+            fr = grp_frames + (int64_t)gi * SRK_GRP_MAXNF_HOST;
+            for (int l = lane; l < n_pts; l += WAVE) {
+                sTOff[wv][l] = (int32_t)(row_ptr[first_pt + l] - o_base);
+                sTMask[wv][l] = pt_mask[first_pt + l];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (one wave: its LDS operations execute in order)
+        }
         const int g = WAVE / nf, active = g * nf;
         const int m = lane / nf, f = lane - m * nf;
         const bool on = lane < active;
-        const int js = on ? obs_frame[o_base + f] - jmin : 0;
+        const int js = on ? (MASKED ? fr[f] : obs_frame[o_base + f]) - jmin : 0;
+        // the observation of cell (landmark il of the task, this lane's slot): MASKED -> from the table, else il nf + f
+        auto cell = [&](int il, bool& seen) -> int64_t {
+            if constexpr (MASKED) {
+                const uint32_t mk = sTMask[wv][il];
+                seen = (mk >> f) & 1u;
+                return o_base + sTOff[wv][il] + __builtin_popcount(mk & ((1u << f) - 1u));
+            } else {
+                seen = true;
+                return o_base + (int64_t)il * nf + f;
+            }
+        };
         const double* c = sCam[js];
         double* sr = sR[wv];
         double acc[SRK_UG];
@@ -511,20 +542,25 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
         // software pipeline: the next iteration's observation and landmark are loaded while this one is computed
         double2 uv_n = make_double2(0, 0);
         double Xn0 = 0, Xn1 = 0, Xn2 = 0;
+        bool seen_n = false;
+        int64_t o_n = 0;
         if (on && step_first * g + m < n_pts) {
-            uv_n = reinterpret_cast<const double2*>(obs_uv)[o_base + (int64_t)(step_first * g + m) * nf + f];
+            o_n = cell(step_first * g + m, seen_n);
+            if (seen_n) uv_n = reinterpret_cast<const double2*>(obs_uv)[o_n];
             const double* X = pts + 3 * (int64_t)(first_pt + step_first * g + m);
             Xn0 = X[0]; Xn1 = X[1]; Xn2 = X[2];
         }
 #pragma unroll 1
         for (int i0 = step_first * g; i0 < n_pts; i0 += step_stride * g) {
             const int il = i0 + m;
-            const bool valid = on && il < n_pts;
-            const int64_t o = o_base + (int64_t)il * nf + f;
+            const bool valid = on && il < n_pts && seen_n;
+            const int64_t o = o_n;
             const double2 uv = uv_n;
             const double X0 = Xn0, X1 = Xn1, X2 = Xn2;
+            seen_n = false;
             if (on && il + step_stride * g < n_pts) {
-                uv_n = reinterpret_cast<const double2*>(obs_uv)[o + (int64_t)step_stride * g * nf];
+                o_n = cell(il + step_stride * g, seen_n);
+                if (seen_n) uv_n = reinterpret_cast<const double2*>(obs_uv)[o_n];
                 const double* X = pts + 3 * (int64_t)(first_pt + il + step_stride * g);
                 Xn0 = X[0]; Xn1 = X[1]; Xn2 = X[2];
             }
@@ -635,16 +671,19 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
 void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, const double* cam, const int64_t* row_ptr,
                          const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
                          const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
-                         int /* min_nf: shortest frame list of any task (not needed by this version) */)
+                         const int32_t* task_group, const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask)
 {
     if (n_tasks <= 0) return;
     const dim3 grid((unsigned)((n_tasks + 3) / 4));
-    if (d.w_f32)
-        hipLaunchKernelGGL(k_jac_runs<float>, grid, dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame, obs_uv,
-                           reinterpret_cast<float*>(W), Vg, Ug, task_first, task_count, n_tasks, wg_jmin);
-    else
-        hipLaunchKernelGGL(k_jac_runs<double>, grid, dim3(256), 0, s, d, pts, cam, row_ptr, obs_frame, obs_uv, W, Vg, Ug,
-                           task_first, task_count, n_tasks, wg_jmin);
+#define SRK_JR_ARGS(WP) d, pts, cam, row_ptr, obs_frame, obs_uv, WP, Vg, Ug, task_first, task_count, n_tasks, wg_jmin, task_group, grp_nf, grp_frames, pt_mask
+    if (task_group) { // tasks over unions of frame lists (ragged tracks)
+        if (d.w_f32) hipLaunchKernelGGL((k_jac_runs<float, true>), grid, dim3(256), 0, s, SRK_JR_ARGS(reinterpret_cast<float*>(W)));
+        else hipLaunchKernelGGL((k_jac_runs<double, true>), grid, dim3(256), 0, s, SRK_JR_ARGS(W));
+    } else {
+        if (d.w_f32) hipLaunchKernelGGL((k_jac_runs<float, false>), grid, dim3(256), 0, s, SRK_JR_ARGS(reinterpret_cast<float*>(W)));
+        else hipLaunchKernelGGL((k_jac_runs<double, false>), grid, dim3(256), 0, s, SRK_JR_ARGS(W));
+    }
+#undef SRK_JR_ARGS
 }
 
 void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
