@@ -467,7 +467,7 @@ def main():
                     "traffic": tr, "traffic_source": pmc_source if tr is not None else None, "ms": ms,
                     "algorithmic_bytes": bytes_}
 
-        jac_names = {2: ("k_jac_runs",), 1: ("k_jac_fused",), 0: ("k_jac_points", "k_jac_frames")}.get(jac_kernel, ())
+        jac_names = {3: ("k_jac_runs",), 2: ("k_jac_runs",), 1: ("k_jac_fused",), 0: ("k_jac_points", "k_jac_frames")}.get(jac_kernel, ())
         # (fp64 storage keeps the point-frame blocks as their 21 rank-2 factors: the derivative pass WRITES and the Schur and
         # back-substitution passes READ 168 instead of SURVEY 8(d)'s 240 bytes per observation; `achieved` stays on the
         # algorithmic figure, `stored_bytes` says what the layout moves)

@@ -287,8 +287,11 @@ int srk_frame_order(int mode, int64_t n_points, int32_t n_frames, const int64_t*
 /* Derivative kernel selection (harness knob, the reference has one code path: bundle-adj-kanatani.cpp:1140-1448).
  * mode -1 = automatic: the run-based kernel (a lane keeps one frame's sums in registers over a run of landmarks with
  * identical frame lists) when the runs are long enough, else the per-observation kernels; 0 = per-observation kernels
- * only; 1 = run-based whenever the scene allows it (tracks of <= 64 frames, narrow frame windows).  Takes effect at the next upload.  srk_ba_jacobian_kernel: 2 = run-based, 1 = fused per-observation,
- * 0 = two-kernel path, -1 = no scene. */
+ * only; 1 = run-based whenever the scene allows it (tracks of <= 64 frames, narrow frame windows); 2 = run-based over the
+ * UNION of the frame lists of a run of landmarks (ragged feature tracks: a lane per (landmark, frame slot) cell, masks) whenever
+ * the scene allows it (every track of <= 24 frames) -- automatic mode takes it when the uniform runs are too short to pay.
+ * Takes effect at the next upload.  srk_ba_jacobian_kernel: 3 = run-based over frame unions, 2 = run-based, 1 = fused
+ * per-observation, 0 = two-kernel path, -1 = no scene. */
 int srk_ba_set_jacobian_mode(srk_ba*, int mode);
 int srk_ba_jacobian_kernel(srk_ba*);
 

@@ -327,7 +327,8 @@ class BundleAdjustmentKanatani:
         return int(self._lib.srk_ba_solver_sync_timeouts(C.c_void_p(self._h)))
 
     def set_jacobian_mode(self, mode=-1):
-        """-1 automatic, 0 = per-observation kernels only, 1 = run-based whenever possible (next upload)"""
+        """-1 automatic, 0 = per-observation kernels only, 1 = run-based (uniform runs) whenever possible, 2 = run-based over
+        frame unions (ragged tracks) whenever possible (next upload)"""
         self._raise(self._lib.srk_ba_set_jacobian_mode(C.c_void_p(self._h), C.c_int(mode)))
 
     def jacobian_kernel(self):

@@ -1205,8 +1205,10 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         i = j;
     }
     if (h->jac_runs) {
-        // long enough to pay: a task flushes 65 sums per lane, which an iteration of the per-observation kernel costs
-        if (jr_first.empty() || (h->jac_mode != 1 && O / (int64_t)jr_first.size() < 256)) h->jac_runs = false;
+        // long enough to pay: a task flushes 65 sums per lane, which an iteration of the per-observation kernel costs.
+        // (Round 3, tools/jac_modes.py: at 240 observations a task -- C2 -- the run kernel takes 45 us where the fused
+        // per-observation kernel takes 64; tasks of one or two ragged landmarks, ~20 observations, 118 against 69.)
+        if (jr_first.empty() || (h->jac_mode != 1 && O / (int64_t)jr_first.size() < 128)) h->jac_runs = false;
         for (size_t t0 = 0; t0 < jr_first.size() && h->jac_runs; t0 += 4) {
             int32_t lo = M, hi = -1;
             for (size_t t = t0; t < std::min(jr_first.size(), t0 + 4); ++t) {
@@ -1223,7 +1225,10 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     // kernel with a lane per (landmark, frame slot) CELL: tasks = pieces of those runs.  Needs every landmark in a run.
     std::vector<int32_t> jr_group;
     h->jac_runs_masked = false;
-    if (!h->jac_runs && h->jac_mode != 0 && O < (int64_t)1 << 27 && long_cand.empty() && gen_list.empty() && !grp_first.empty()) {
+    if ((!h->jac_runs || h->jac_mode == 2) && h->jac_mode != 0 && O < (int64_t)1 << 27 && long_cand.empty() && gen_list.empty() && !grp_first.empty()) {
+        const bool uniform_ok = h->jac_runs; // (mode 2: the union tasks are preferred, the uniform ones stay as the fallback)
+        std::vector<int32_t> u_first, u_count, u_jmin;
+        u_first.swap(jr_first); u_count.swap(jr_count); u_jmin.swap(jr_jmin);
         jr_first.clear();
         jr_count.clear();
         jr_jmin.clear();
@@ -1238,7 +1243,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
                 jr_group.push_back((int32_t)gi);
             }
         }
-        bool ok = h->jac_mode == 1 || O / (int64_t)jr_first.size() >= 256;
+        bool ok = h->jac_mode >= 1 || O / (int64_t)jr_first.size() >= 32; // (the dino stand-in: 40 a task, 31 against 60 us)
         for (size_t t0 = 0; t0 < jr_first.size() && ok; t0 += 4) {
             int32_t lo = M, hi = -1;
             for (size_t t = t0; t < std::min(jr_first.size(), t0 + 4); ++t) {
@@ -1249,7 +1254,13 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             if (hi - lo >= SRK_JF_SLOTS_HOST) ok = false;
             jr_jmin.push_back(lo);
         }
-        h->jac_runs = h->jac_runs_masked = ok;
+        h->jac_runs_masked = ok;
+        if (!ok) { // back to the uniform tasks (if they were usable)
+            jr_first.swap(u_first); jr_count.swap(u_count); jr_jmin.swap(u_jmin);
+            jr_group.clear();
+            h->jac_runs = uniform_ok;
+        } else
+            h->jac_runs = true;
     }
     h->jr_tasks = h->jac_runs ? (int32_t)jr_first.size() : 0;
 
@@ -2855,14 +2866,15 @@ int srk_frame_order(int mode, int64_t N, int32_t M, const int64_t* row_ptr, cons
 }
 
 // -1 = automatic (run-based kernel when the runs of identical frame lists are long enough), 0 = per-observation kernels
-// only, 1 = run-based whenever the scene allows it; takes effect at the next upload.  For A/B runs and for the parity tests of both kernels on the same scene.
+// only, 1 = run-based (uniform runs) whenever the scene allows it, 2 = run-based over frame unions (the ragged-track form)
+// whenever the scene allows it; takes effect at the next upload.  For A/B runs and for the parity tests of both kernels on the same scene.
 int srk_ba_set_jacobian_mode(srk_ba* h, int mode)
 {
-    if (!h || mode < -1 || mode > 1) return SRK_E_ARGS;
+    if (!h || mode < -1 || mode > 2) return SRK_E_ARGS;
     h->jac_mode = mode;
     return SRK_OK;
 }
-int srk_ba_jacobian_kernel(srk_ba* h) { return (h && h->have_scene) ? (h->jac_runs ? 2 : (h->jac_fused ? 1 : 0)) : -1; }
+int srk_ba_jacobian_kernel(srk_ba* h) { return (h && h->have_scene) ? (h->jac_runs ? (h->jac_runs_masked ? 3 : 2) : (h->jac_fused ? 1 : 0)) : -1; }
 
 // 0 = everything stored in fp64 (default, the reference's Scalar = double); 1 = the point-frame blocks W -- 240 of the
 // 260 bytes per observation the derivative kernel writes and the Schur and back-substitution kernels read -- are stored

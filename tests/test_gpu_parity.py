@@ -299,6 +299,55 @@ def test_run_based_derivative_kernel_on_golden_inputs_and_ragged_tracks(orc, gpu
         gpu.set_jacobian_mode(-1)
 
 
+UNION_RUN_SCENES = {
+    # tasks = pieces of the Schur kernel's runs over the UNION of their landmarks' frame lists; a lane per (landmark, slot) cell
+    "ragged_7": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7)), 0.25, seed=3),
+    "ragged_20": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=60, grid_nx=40, grid_ny=30, vis_window=20)), 0.15, seed=5),
+    "ragged_13_noise": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=40, grid_nx=30, grid_ny=20, vis_window=13, noise_uv_pix=0.4)), 0.4, seed=7),
+    "uniform_nf16": lambda: sa.generate_scene(JAC_RUN_SCENES["nf16"]),             # full masks: the uniform case of the same code
+    "uniform_nf3": lambda: sa.generate_scene(JAC_RUN_SCENES["nf3_many_per_iteration"]),
+    "two_observations_each": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=20, grid_nx=15, grid_ny=12, vis_window=9)), 0.9, seed=1),
+}
+
+
+@pytest.mark.parametrize("name", list(UNION_RUN_SCENES))
+@pytest.mark.parametrize("c", [1e-4, 10.0])
+def test_run_based_derivative_kernel_over_frame_unions_vs_oracle(orc, gpu, name, c):
+    """Ragged tracks through k_jac_runs<MASKED>: blocks rel 1e-12, gradient rel 1e-10 against the oracle and the whole chain
+    behind it (bundle-adj-kanatani.cpp:1140-1448); automatic mode picks this form when uniform runs are too short to pay."""
+    sc = UNION_RUN_SCENES[name]()
+    gpu.set_jacobian_mode(2)
+    try:
+        out = _phases(orc, gpu, sc, 600.0, c)
+        assert gpu.jacobian_kernel() == 3
+        _check(out, sc.M, corr_tol=1e-7)
+    finally:
+        gpu.set_jacobian_mode(-1)
+
+
+def test_automatic_mode_takes_the_union_form_on_ragged_tracks_of_bench_density(gpu):
+    """200 frames, 20 000 landmarks, 20-frame tracks with 10 % of the observations dropped: hardly two landmarks see the same
+    frames (uniform tasks of one or two landmarks), the union tasks hold ~100.  The two derivative kernels agree."""
+    sc = sa.drop_observations(sa.config_scene("C2_200cam_20kpt"), 0.1, seed=0)
+    f0 = sa.CONFIGS["C2_200cam_20kpt"].f0
+    res = {}
+    for mode in (-1, 0):
+        gpu.set_jacobian_mode(mode)
+        assert gpu.upload(f0, sc)
+        res[mode] = gpu.jacobian_kernel()
+        gpu.phase_error()
+        gpu.phase_derivatives()
+        res[mode, "V"] = gpu.buffer(B.BUF_POINT_BLOCKS)
+        res[mode, "U"] = gpu.buffer(B.BUF_FRAME_BLOCKS)
+        res[mode, "W"] = gpu.buffer(B.BUF_POINT_FRAME)
+        res[mode, "g"] = gpu.buffer(B.BUF_GRAD)
+    gpu.set_jacobian_mode(-1)
+    assert res[-1] == 3 and res[0] in (0, 1)
+    assert rel_err(res[-1, "W"], res[0, "W"]) < 1e-13
+    assert rel_err(res[-1, "V"], res[0, "V"]) < 1e-13 and rel_err(res[-1, "U"], res[0, "U"]) < 1e-12
+    assert rel_err(res[-1, "g"], res[0, "g"]) < 1e-10
+
+
 def test_derivative_kernels_agree_at_bench_size(gpu):
     """BASELINE config 3 (the bench workload): the run-based kernel (picked automatically there) and the per-observation
     fused kernel give the same blocks to rounding (different summation orders), landmark by landmark."""
