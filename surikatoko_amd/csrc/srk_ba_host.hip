@@ -25,6 +25,7 @@
 #include <vector>
 #include <functional>
 #include <unordered_set>
+#include <thread>
 
 namespace {
 
@@ -98,6 +99,7 @@ struct srk_ba {
         std::vector<DevBuf> plan_bufs;
         std::vector<char> plan_zeroed;   // plan_bufs[i] is a matrix / vector that must be zero outside what a solve writes
         std::vector<std::unique_ptr<SrkChunkPlan>> plan_children; // plans of the nested separator systems
+        std::vector<int64_t> plan_sig;   // what the plan was built for (build_chunk_plan keeps it when the next scene's skyline is the same)
         SrkSolveProf solve_prof;     // event pairs / flops of the last profiled solve
         double* host_back = nullptr; // pinned: {error, solver info, point-update info} of one attempt
         hipStream_t stream = nullptr;
@@ -696,6 +698,17 @@ static int build_chunk_plan(srk_ba* h)
 {
     const SrkDims& d = h->d;
     SrkChunkPlan& pl = h->A->plan;
+    // the same skyline as the plan in place was built for (a scene uploaded again, the next call of a caller that adjusts the
+    // same tracks): keep plan and buffers -- freeing and allocating them again costs ~9 ms a slot at 1000 frames -- and
+    // bring the buffers that must be zero outside what a solve writes back to zero
+    std::vector<int64_t> sig = { d.ld, h->use_envelope ? 1 : 0, h->use_chunks ? 1 : 0 };
+    sig.insert(sig.end(), h->min_cv.begin(), h->min_cv.end());
+    if (!h->A->plan_sig.empty() && sig == h->A->plan_sig) {
+        for (size_t i = 0; i < h->A->plan_bufs.size(); ++i)
+            if (h->A->plan_zeroed[i]) HIPCHK(h, hipMemsetAsync(h->A->plan_bufs[i].p, 0, h->A->plan_bufs[i].bytes, h->stream));
+        return SRK_OK;
+    }
+    h->A->plan_sig = sig;
     pl.P = 0;
     pl.child = nullptr;
     for (DevBuf& b : h->A->plan_bufs) dev_free(b);
@@ -708,7 +721,9 @@ static int build_chunk_plan(srk_ba* h)
     // separators at least one bandwidth wide, in units of the 256-column outer panel (k_bwd_border stages 2 sepw values)
     const int64_t sepw = (maxdist + SRK_CHOL_NB - 1) / SRK_CHOL_NB * SRK_CHOL_NB;
     if (sepw > SRK_MAX_SEPW) return SRK_OK;
-    return make_plan(h, pl, d.ld, sepw, SRK_CHOL_NB, h->row_end_h, h->col_begin_h);
+    const int rc = make_plan(h, pl, d.ld, sepw, SRK_CHOL_NB, h->row_end_h, h->col_begin_h);
+    if (rc != SRK_OK) h->A->plan_sig.clear();
+    return rc;
 }
 
 // Skyline of the RCS from the covisibility (min_cv[j] = smallest frame index sharing a landmark with frame j).
@@ -883,9 +898,17 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
                                    const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
                                    int already_normalized)
 {
+    auto t_stage = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) { // SRK_DEBUG=1: where the host time of an upload goes
+        if (!srk_debug()) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "srk_ba upload: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_stage).count());
+        t_stage = now;
+    };
     int rc = validate_scene(h, f0, N, pts_in, M, cam_R_in, cam_T_in, K_in, row_ptr, obs_frame, obs_uv);
     if (rc != SRK_OK) return rc;
     rearm_fusion(h);
+    stage("validate");
     HIPCHK(h, hipSetDevice(h->device));
     h->have_scene = false;
     h->seen_global = -1;
@@ -978,25 +1001,59 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             if (obs_frame[ox + k] != obs_frame[oy + k]) return obs_frame[ox + k] < obs_frame[oy + k];
         return false;
     };
-    std::stable_sort(order.begin(), order.end(), list_less);
+    stage("normalise, frame order");
+    // (large scenes: chunks sorted by a few host threads, then merged pairwise -- both stable, so the order is the one a
+    // single stable_sort gives)
+    const int n_thr = N >= 32768 ? (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency())) : 1;
+    if (n_thr > 1) {
+        std::vector<int64_t> cut((size_t)n_thr + 1);
+        for (int t = 0; t <= n_thr; ++t) cut[(size_t)t] = N * t / n_thr;
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; ++t)
+            th.emplace_back([&, t] { std::stable_sort(order.begin() + cut[(size_t)t], order.begin() + cut[(size_t)t + 1], list_less); });
+        for (auto& x : th) x.join();
+        for (int w = 1; w < n_thr; w *= 2) {
+            th.clear();
+            for (int t = 0; t + w < n_thr; t += 2 * w)
+                th.emplace_back([&, t, w] {
+                    std::inplace_merge(order.begin() + cut[(size_t)t], order.begin() + cut[(size_t)(t + w)],
+                                       order.begin() + cut[(size_t)std::min(t + 2 * w, n_thr)], list_less);
+                });
+            for (auto& x : th) x.join();
+        }
+    } else
+        std::stable_sort(order.begin(), order.end(), list_less);
+    stage("sort landmarks by frame list");
     h->perm = order;
     h->row_ptr_user.assign(row_ptr, row_ptr + N + 1);
     std::vector<int64_t> rp((size_t)N + 1, 0);
     std::vector<int32_t> of((size_t)O);
     std::vector<double> ouv((size_t)(2 * O)), ppts((size_t)(3 * N));
     for (int64_t i = 0; i < N; ++i) {
-        int64_t u = order[(size_t)i];
-        int64_t cnt = row_ptr[u + 1] - row_ptr[u];
-        rp[(size_t)i + 1] = rp[(size_t)i] + cnt;
-        std::memcpy(&of[(size_t)rp[(size_t)i]], obs_frame + row_ptr[u], (size_t)(4 * cnt));
-        std::memcpy(&ouv[(size_t)(2 * rp[(size_t)i])], obs_uv + 2 * row_ptr[u], (size_t)(16 * cnt));
-        std::memcpy(&ppts[(size_t)(3 * i)], &pts[(size_t)(3 * u)], 24);
+        const int64_t u = order[(size_t)i];
+        rp[(size_t)i + 1] = rp[(size_t)i] + (row_ptr[u + 1] - row_ptr[u]);
     }
+    auto permute_range = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            const int64_t u = order[(size_t)i];
+            const int64_t cnt = row_ptr[u + 1] - row_ptr[u];
+            std::memcpy(&of[(size_t)rp[(size_t)i]], obs_frame + row_ptr[u], (size_t)(4 * cnt));
+            std::memcpy(&ouv[(size_t)(2 * rp[(size_t)i])], obs_uv + 2 * row_ptr[u], (size_t)(16 * cnt));
+            std::memcpy(&ppts[(size_t)(3 * i)], &pts[(size_t)(3 * u)], 24);
+        }
+    };
+    if (n_thr > 1) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; ++t) th.emplace_back(permute_range, N * t / n_thr, N * (t + 1) / n_thr);
+        for (auto& x : th) x.join();
+    } else
+        permute_range(0, N);
     h->row_ptr_int = rp;
     pts.swap(ppts);
     row_ptr = rp.data();
     obs_frame = of.data();
     obs_uv = ouv.data();
+    stage("permute observations");
     // Runs of consecutive landmarks (internal order) whose frame lists fit a common set of <= SRK_GRP_MAXNF_HOST
     // frames -> grouped Schur kernel: the run's blocks are accumulated over that UNION of frames, a landmark that does
     // not see one of them contributes zeros there.  Identical lists (the circle-grid scenes) are the special case
@@ -1018,6 +1075,8 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             while (j < N && j - i < SRK_GRP_MAXPTS_HOST) {
                 const int64_t nfj = rp[(size_t)j + 1] - rp[(size_t)j];
                 if (nfj == 0 || nfj > cap) break;
+                // (the common case first: the same frame list as the run so far -- nothing to merge)
+                if (nfj == (int64_t)uni.size() && std::equal(uni.begin(), uni.end(), of.begin() + rp[(size_t)j])) { ++j; continue; }
                 merged.clear();
                 std::set_union(uni.begin(), uni.end(), of.begin() + rp[(size_t)j], of.begin() + rp[(size_t)j + 1],
                                std::back_inserter(merged));
@@ -1031,13 +1090,18 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
             bool uniform = true;
             for (int64_t p = i; p < j; ++p) {
                 uint32_t mask = 0;
-                for (int64_t o = rp[(size_t)p]; o < rp[(size_t)p + 1]; ++o) {
-                    int slot = (int)(std::lower_bound(uni.begin(), uni.end(), of[(size_t)o]) - uni.begin());
-                    obs_slot[(size_t)o] = (uint8_t)slot;
-                    mask |= 1u << slot;
+                if (rp[(size_t)p + 1] - rp[(size_t)p] == (int64_t)uni.size()) { // as many frames as the union: the union itself
+                    for (int64_t o = rp[(size_t)p], k = 0; o < rp[(size_t)p + 1]; ++o, ++k) obs_slot[(size_t)o] = (uint8_t)k;
+                    mask = (uint32_t)((1ull << uni.size()) - 1);
+                } else {
+                    for (int64_t o = rp[(size_t)p]; o < rp[(size_t)p + 1]; ++o) {
+                        int slot = (int)(std::lower_bound(uni.begin(), uni.end(), of[(size_t)o]) - uni.begin());
+                        obs_slot[(size_t)o] = (uint8_t)slot;
+                        mask |= 1u << slot;
+                    }
+                    uniform = false;
                 }
                 pt_mask[(size_t)p] = mask;
-                uniform = uniform && (rp[(size_t)p + 1] - rp[(size_t)p] == (int64_t)uni.size());
             }
             grp_first.push_back((int32_t)i);
             grp_count.push_back((int32_t)(j - i));
@@ -1127,6 +1191,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     h->d = d;
     h->f0 = f0;
 
+    stage("Schur runs");
     // observation side tables: obs -> point, and the frame-major copy (ordered by frame, then landmark)
     std::vector<int32_t> obs_pt((size_t)O);
     std::vector<int64_t> col_ptr((size_t)M + 1, 0);
@@ -1139,17 +1204,6 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     for (int32_t j = 0; j < M; ++j) {
         if (col_ptr[(size_t)j + 1] > h->max_frame_obs) h->max_frame_obs = col_ptr[(size_t)j + 1];
         col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
-    }
-    std::vector<int32_t> fobs_pt((size_t)O);
-    std::vector<double> fobs_uv((size_t)(2 * O));
-    {
-        std::vector<int64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
-        for (int64_t o = 0; o < O; ++o) {
-            int64_t k = fill[(size_t)obs_frame[o]]++;
-            fobs_pt[(size_t)k] = obs_pt[(size_t)o];
-            fobs_uv[(size_t)(2 * k)] = obs_uv[2 * o];
-            fobs_uv[(size_t)(2 * k + 1)] = obs_uv[2 * o + 1];
-        }
     }
 
     // frame range of every SRK_JF_OBS_HOST-observation workgroup of the fused Jacobian kernel
@@ -1167,6 +1221,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
         wg_jmin.push_back(lo);
     }
 
+    stage("side tables, frame windows");
     // tasks of the run-based Jacobian kernel: maximal runs of consecutive landmarks (internal order) with identical
     // frame lists, cut into pieces (a multiple of the landmarks per step).  The kernel holds two 4-wave workgroups per
     // CU (a wave keeps 61 frame sums and a step of look-ahead in ~250 registers); with about one task per wave slot
@@ -1264,6 +1319,20 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     }
     h->jr_tasks = h->jac_runs ? (int32_t)jr_first.size() : 0;
 
+    // the frame-major copy of the observations (ordered by frame, then landmark): only the two-kernel derivative path reads it
+    const bool need_frame_major = !h->jac_runs && !h->jac_fused;
+    std::vector<int32_t> fobs_pt(need_frame_major ? (size_t)O : 0);
+    std::vector<double> fobs_uv(need_frame_major ? (size_t)(2 * O) : 0);
+    if (need_frame_major) {
+        std::vector<int64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+        for (int64_t o = 0; o < O; ++o) {
+            int64_t k = fill[(size_t)obs_frame[o]]++;
+            fobs_pt[(size_t)k] = obs_pt[(size_t)o];
+            fobs_uv[(size_t)(2 * k)] = obs_uv[2 * o];
+            fobs_uv[(size_t)(2 * k + 1)] = obs_uv[2 * o + 1];
+        }
+    }
+    stage("derivative tasks");
 #define ALLOC(buf, bytes)                              \
     do {                                               \
         int _r = dev_alloc(h, (buf), (size_t)(bytes)); \
@@ -1290,8 +1359,8 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->obs_pt, 4 * O);
     ALLOC(h->obs_uv, 16 * O);
     ALLOC(h->col_ptr, 8 * ((int64_t)M + 1));
-    ALLOC(h->fobs_pt, 4 * O);
-    ALLOC(h->fobs_uv, 16 * O);
+    ALLOC(h->fobs_pt, 4 * fobs_pt.size());
+    ALLOC(h->fobs_uv, 8 * fobs_uv.size());
     ALLOC(h->W, d.w_f32 ? 4 * 30 * d.Os : 8 * SRK_WF_PLANES * d.Os); // f32: the 30 products; fp64: their 21 rank-2 factors
     ALLOC(h->Vg, 8 * 9 * d.Ns);
     ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
@@ -1341,6 +1410,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     }
 #undef ALLOC
     hipStream_t s = h->stream;
+    stage("device allocations");
 #define H2D(buf, src, bytes)                                                                               \
     do {                                                                                                   \
         if ((bytes) > 0) HIPCHK(h, hipMemcpyAsync((buf).p, (src), (size_t)(bytes), hipMemcpyHostToDevice, s)); \
@@ -1357,8 +1427,8 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     H2D(h->obs_pt, obs_pt.data(), 4 * O);
     H2D(h->obs_uv, obs_uv, 16 * O);
     H2D(h->col_ptr, col_ptr.data(), 8 * ((int64_t)M + 1));
-    H2D(h->fobs_pt, fobs_pt.data(), 4 * O);
-    H2D(h->fobs_uv, fobs_uv.data(), 16 * O);
+    H2D(h->fobs_pt, fobs_pt.data(), 4 * fobs_pt.size());
+    H2D(h->fobs_uv, fobs_uv.data(), 8 * fobs_uv.size());
     H2D(h->grp_first, grp_first.data(), 4 * grp_first.size());
     H2D(h->grp_count, grp_count.data(), 4 * grp_count.size());
     H2D(h->grp_nf, grp_nf.data(), 4 * grp_nf.size());
@@ -1403,8 +1473,10 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
                 h->min_cv[(size_t)obs_frame[o]] = std::min(h->min_cv[(size_t)obs_frame[o]], first);
         }
     }
+    stage("host-to-device copies");
     rc = build_envelope(h);
     if (rc != SRK_OK) return rc;
+    stage("skyline, solver plans");
     h->have_scene = true;
     return SRK_OK;
 }
