@@ -471,7 +471,7 @@ def main():
         # (fp64 storage keeps the point-frame blocks as their 21 rank-2 factors: the derivative pass WRITES and the Schur and
         # back-substitution passes READ 168 instead of SURVEY 8(d)'s 240 bytes per observation; `achieved` stays on the
         # algorithmic figure, `stored_bytes` says what the layout moves)
-        w_stored = 120 if args.store_f32 else 168
+        w_stored = 84 if args.store_f32 else 168  # the 21 rank-2 factors of a point-frame block, as floats or doubles
         kernels = {
             "jacobian_phase": hbm(ab["jacobian"], per_it["ms_jacobian"], *jac_names),
             "jacobian_kernel": hbm(ab["jacobian"], per_it["ms_jacobian_kernel"], *jac_names),

@@ -298,8 +298,8 @@ int srk_ba_jacobian_kernel(srk_ba*);
 /* f32 storage mode (the reference's suriko_scalar_type_string = f32 switch, suriko-engine/
  * CMakeLists.txt:14-15,76-82, rt-config.h:41-48, applied where the bytes are): f32 = 1 stores the point-frame blocks W
  * (3 x 10 per observation: 240 of the 260 algorithmic bytes per observation of the derivative pass, and what the Schur
- * and back-substitution passes read) as float; they are widened on load, every sum, the reduced camera system and the
- * solve stay fp64.  Takes effect at the next upload.  Tolerances against the fp64 path and against the oracle with W
+ * and back-substitution passes read; the library keeps each block as its 21 rank-2 factors) as float, 84 bytes an
+ * observation; they are widened on load, every sum, the reduced camera system and the solve stay fp64.  Takes effect at the next upload.  Tolerances against the fp64 path and against the oracle with W
  * rounded the same way: tests/test_gpu_parity.py::test_f32_storage_*.  Default 0. */
 int srk_ba_set_storage_precision(srk_ba*, int f32);
 

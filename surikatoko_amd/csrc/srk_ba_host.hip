@@ -1361,7 +1361,7 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     ALLOC(h->col_ptr, 8 * ((int64_t)M + 1));
     ALLOC(h->fobs_pt, 4 * fobs_pt.size());
     ALLOC(h->fobs_uv, 8 * fobs_uv.size());
-    ALLOC(h->W, d.w_f32 ? 4 * 30 * d.Os : 8 * SRK_WF_PLANES * d.Os); // f32: the 30 products; fp64: their 21 rank-2 factors
+    ALLOC(h->W, (d.w_f32 ? 4 : 8) * SRK_WF_PLANES * d.Os); // the 21 rank-2 factors of every point-frame block, fp64 or (opt-in) float
     ALLOC(h->Vg, 8 * 9 * d.Ns);
     ALLOC(h->Ug, 8 * SRK_UG * (int64_t)M);
     select_attempt(h, 0);
@@ -2654,14 +2654,14 @@ int srk_ba_download(srk_ba* h, int which, double* dst, int64_t count)
     }
     case SRK_BUF_POINT_FRAME: {
         std::vector<double> w((size_t)(30 * d.Os));
-        if (d.w_f32) {
-            std::vector<float> wf((size_t)(30 * d.Os));
-            if ((rc = d2h(wf.data(), h->W.p, wf.size() * 4)) != SRK_OK) return rc;
-            for (size_t i = 0; i < wf.size(); ++i) w[i] = (double)wf[i];
-        } else {
-            // fp64 storage keeps the rank-2 factors (srk_dev.hpp SRK_WF_*): the products are formed here
+        {
+            // the library keeps the rank-2 factors (srk_dev.hpp SRK_WF_*; as floats in the f32 storage mode): the products are formed here
             std::vector<double> f((size_t)(SRK_WF_PLANES * d.Os));
-            if ((rc = d2h(f.data(), h->W.p, f.size() * 8)) != SRK_OK) return rc;
+            if (d.w_f32) {
+                std::vector<float> ff(f.size());
+                if ((rc = d2h(ff.data(), h->W.p, ff.size() * 4)) != SRK_OK) return rc;
+                for (size_t i = 0; i < ff.size(); ++i) f[i] = (double)ff[i];
+            } else if ((rc = d2h(f.data(), h->W.p, f.size() * 8)) != SRK_OK) return rc;
             auto F = [&](int plane, int64_t o) { return plane >= 0 ? f[(size_t)(plane * d.Os + o)] : 0.0; };
             for (int64_t o = 0; o < d.O; ++o)
                 for (int pv = 0; pv < 3; ++pv)

@@ -68,22 +68,17 @@ void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double
 // -- 3 + 3 + 8 + 7 = 21 doubles (Af[1] = Af[3] = Bf[0] = Bf[2] = 0 and Af[2] = Bf[3]) instead of 30 products, 168 instead
 // of 240 bytes an observation for the derivative pass to write and the Schur and back-substitution passes to read -- as SoA
 // planes F[k Os + o] (SRK_WF_* in srk_dev.hpp), and every consumer forms the entries it needs with two multiply-adds.
-// The opt-in f32 storage mode keeps the 30 products as floats (120 bytes), as before.
-template <typename WT> struct WStore { static constexpr bool factored = false; };
-template <> struct WStore<double> { static constexpr bool factored = true; };
+// The opt-in f32 storage mode keeps the same 21 factors as floats (84 bytes; arithmetic stays fp64: loads widen).
 // plane of Af[fv] / Bf[fv], or -1 where the factor is structurally zero
 __device__ __forceinline__ int srk_wf_af_plane(int fv) { return fv >= 4 ? SRK_WF_AF4 + fv - 4 : (fv == 0 ? SRK_WF_AF0 : (fv == 2 ? SRK_WF_G : -1)); }
 __device__ __forceinline__ int srk_wf_bf_plane(int fv) { return fv >= 4 ? SRK_WF_BF4 + fv - 4 : (fv == 1 ? SRK_WF_BF1 : (fv == 3 ? SRK_WF_G : -1)); }
 // entry k = 10 pv + fv of observation o, whatever the storage
 template <typename WT> __device__ __forceinline__ double w_entry(const WT* __restrict__ W, int64_t Os, int64_t o, int k)
 {
-    if constexpr (!WStore<WT>::factored) return (double)W[(int64_t)k * Os + o];
-    else {
-        const int pv = k / 10, fv = k - 10 * pv;
-        const int pa = srk_wf_af_plane(fv), pb = srk_wf_bf_plane(fv);
-        const double af = pa >= 0 ? W[(int64_t)pa * Os + o] : 0.0, bf = pb >= 0 ? W[(int64_t)pb * Os + o] : 0.0;
-        return W[(int64_t)(SRK_WF_AP + pv) * Os + o] * af + W[(int64_t)(SRK_WF_BP + pv) * Os + o] * bf;
-    }
+    const int pv = k / 10, fv = k - 10 * pv;
+    const int pa = srk_wf_af_plane(fv), pb = srk_wf_bf_plane(fv);
+    const double af = pa >= 0 ? (double)W[(int64_t)pa * Os + o] : 0.0, bf = pb >= 0 ? (double)W[(int64_t)pb * Os + o] : 0.0;
+    return (double)W[(int64_t)(SRK_WF_AP + pv) * Os + o] * af + (double)W[(int64_t)(SRK_WF_BP + pv) * Os + o] * bf;
 }
 // the block of observation o from factors scaled so that W = Ap Af + Bp Bf
 template <typename WT>
@@ -91,23 +86,13 @@ __device__ __forceinline__ void w_store(WT* __restrict__ W, int64_t Os, int64_t 
                                         const double (&Af)[10], const double (&Bf)[10])
 {
     WT* wp = W + o;
-    if constexpr (WStore<WT>::factored) {
 #pragma unroll
-        for (int v = 0; v < 3; ++v) { wp[(int64_t)(SRK_WF_AP + v) * Os] = Ap[v]; wp[(int64_t)(SRK_WF_BP + v) * Os] = Bp[v]; }
-        wp[(int64_t)SRK_WF_AF0 * Os] = Af[0];
-        wp[(int64_t)SRK_WF_G * Os] = Af[2];
-        wp[(int64_t)SRK_WF_BF1 * Os] = Bf[1];
+    for (int v = 0; v < 3; ++v) { wp[(int64_t)(SRK_WF_AP + v) * Os] = (WT)Ap[v]; wp[(int64_t)(SRK_WF_BP + v) * Os] = (WT)Bp[v]; }
+    wp[(int64_t)SRK_WF_AF0 * Os] = (WT)Af[0];
+    wp[(int64_t)SRK_WF_G * Os] = (WT)Af[2];
+    wp[(int64_t)SRK_WF_BF1 * Os] = (WT)Bf[1];
 #pragma unroll
-        for (int v = 4; v < 10; ++v) { wp[(int64_t)(SRK_WF_AF4 + v - 4) * Os] = Af[v]; wp[(int64_t)(SRK_WF_BF4 + v - 4) * Os] = Bf[v]; }
-    } else {
-#pragma unroll
-        for (int pv = 0; pv < 3; ++pv)
-#pragma unroll
-            for (int fv = 0; fv < 10; ++fv) {
-                *wp = (WT)(Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]);
-                wp += Os;
-            }
-    }
+    for (int v = 4; v < 10; ++v) { wp[(int64_t)(SRK_WF_AF4 + v - 4) * Os] = (WT)Af[v]; wp[(int64_t)(SRK_WF_BF4 + v - 4) * Os] = (WT)Bf[v]; }
 }
 
 // ------------------------------------------------------------------ per-observation geometry
@@ -208,7 +193,7 @@ __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __r
         double Ap[3], Bp[3], Af[10], Bf[10];
         point_ab(c, g, Ap, Bp);
         frame_ab(c, g, X0, X1, X2, Af, Bf);
-        if constexpr (WStore<WT>::factored) {
+        {
             const double sc = 0.7071067811865476 * g.s1; // sqrt(2 / r^4): both sides of every product carry it once
             double Aps[3], Bps[3], Afs[10], Bfs[10];
 #pragma unroll
@@ -216,12 +201,6 @@ __global__ __launch_bounds__(256) void k_jac_points(SrkDims d, const double* __r
 #pragma unroll
             for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * sc; Bfs[v] = Bf[v] * sc; }
             w_store<WT>(W, d.Os, o, Aps, Bps, Afs, Bfs);
-        } else {
-#pragma unroll
-            for (int pv = 0; pv < 3; ++pv)
-#pragma unroll
-                for (int fv = 0; fv < 10; ++fv)
-                    W[(int64_t)(10 * pv + fv) * d.Os + o] = (WT)((Ap[pv] * Af[fv] + Bp[pv] * Bf[fv]) * g.s2);
         }
         acc[0] = (Ap[0] * Ap[0] + Bp[0] * Bp[0]) * g.s2;
         acc[1] = (Ap[0] * Ap[1] + Bp[0] * Bp[1]) * g.s2;
@@ -355,7 +334,7 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
             for (int v = 0; v < 3; ++v) { Aps[v] = Ap[v] * s2; Bps[v] = Bp[v] * s2; }
 #pragma unroll
             for (int v = 0; v < 10; ++v) { Afs[v] = Af[v] * s2; Bfs[v] = Bf[v] * s2; }
-            if constexpr (WStore<WT>::factored) {
+            {
                 const double sc = sqrt(s2); // both sides of every product carry sqrt(2 / r^4) once
                 double Apq[3], Bpq[3], Afq[10], Bfq[10];
 #pragma unroll
@@ -363,15 +342,6 @@ __global__ __launch_bounds__(256) void k_jac_fused(SrkDims d, const double* __re
 #pragma unroll
                 for (int v = 0; v < 10; ++v) { Afq[v] = Af[v] * sc; Bfq[v] = Bf[v] * sc; }
                 w_store<WT>(W, d.Os, o, Apq, Bpq, Afq, Bfq);
-            } else {
-                WT* wp = W + o;
-#pragma unroll
-                for (int pv = 0; pv < 3; ++pv)
-#pragma unroll
-                    for (int fv = 0; fv < 10; ++fv) {
-                        *wp = (WT)(Aps[pv] * Af[fv] + Bps[pv] * Bf[fv]);
-                        wp += d.Os;
-                    }
             }
             acc[0] = Aps[0] * Ap[0] + Bps[0] * Bp[0];
             acc[1] = Aps[0] * Ap[1] + Bps[0] * Bp[1];
@@ -607,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                 const double t0 = X0 - c[30], t1 = X1 - c[31], t2 = X2 - c[32];
                 Af[7] = a1[1] * t2 - a1[2] * t1; Af[8] = a1[2] * t0 - a1[0] * t2; Af[9] = a1[0] * t1 - a1[1] * t0;
                 Bf[7] = b1[1] * t2 - b1[2] * t1; Bf[8] = b1[2] * t0 - b1[0] * t2; Bf[9] = b1[0] * t1 - b1[1] * t0;
-                w_store<WT>(W, d.Os, o, Ap, Bp, Af, Bf); // fp64: the 21 factors; f32 storage: the 30 products
+                w_store<WT>(W, d.Os, o, Ap, Bp, Af, Bf); // the 21 factors (as floats in the f32 storage mode)
                 v9[0] = Ap[0] * Ap[0] + Bp[0] * Bp[0];
                 v9[1] = Ap[0] * Ap[1] + Bp[0] * Bp[1];
                 v9[2] = Ap[0] * Ap[2] + Bp[0] * Bp[2];
@@ -1494,16 +1464,14 @@ __global__ __launch_bounds__(SRK_GRP_THREADS) void k_schur_ws(
 // ------------------------------------------------------------------ K3m: the run's sum as an fp64 MFMA product
 // SQ counters of the register-tile kernels above (tools/schur_pmc.sh): LDS array 65 % busy, a quarter of that bank
 // conflicts, vector ALU 50 % -- every FMA operand is an LDS read (0.3-0.4 doubles per FMA).  But the sum over a run's
-// landmarks IS a matrix product: with the run's W_i stacked as rows k = (landmark, point coordinate) and Y likewise,
-//     sum_i W_i^T E_i^-1 W_i = Wl^T Yl,   Wl, Yl: (3 np) x (10 nf),
-// a (10 nf) x (10 nf) x (3 np) fp64 GEMM.  v_mfma_f64_16x16x4 has the vector pipe's peak (78.6 TFLOP/s) but reads
-// 2 operand doubles per 16 FMAs of a lane, so neither LDS nor instruction issue limits it.  12 waves own the <= 91
-// 16x16 tiles on and below the diagonal of the 13 x 13 tile grid (8 a wave); four helper waves stage W (round r + 2),
-// form Y = E^-1 W (round r + 1) and keep the global loads of round r + 3 in flight while round r is multiplied -- one
-// barrier a round of four landmarks = three K = 4 steps.  Rows of the round buffers are k, columns the frame
-// variables, row stride 208 doubles (= 16 mod 32: the four k rows an MFMA operand spans hit different banks).
-// The element of the lower BLOCK triangle that lies above the TILE diagonal (a 10x10 diagonal block cut by a tile
-// boundary) is taken from its mirror image: the sum is symmetric.
+// landmarks IS a matrix product: with E_i = L_i L_i^T and the run's Z_i = L_i^-1 W_i stacked as rows k = (landmark, point
+// coordinate),
+//     sum_i W_i^T E_i^-1 W_i = Z^T Z,   Z: (3 np) x (10 nf),
+// a (10 nf) x (10 nf) x (3 np) fp64 SYRK.  v_mfma_f64_16x16x4 has the vector pipe's peak (78.6 TFLOP/s) but reads
+// 2 operand doubles per 16 FMAs of a lane.  Rows of the round buffers are k, columns the frame variables, row stride 208
+// doubles (= 16 mod 32: the four k rows an MFMA operand spans hit different banks).  The element of the lower BLOCK triangle
+// that lies above the TILE diagonal (a 10x10 diagonal block cut by a tile boundary) is taken from its mirror image: the sum
+// is symmetric.  Roles, rounds and what was measured: at the kernel (k_schur_mm) below.
 #ifdef SRK_MM_STAMPS // development (tools/mm_stamps.sh): in-kernel clock stamps of one multiplier and one loader lane
 __device__ long long g_mm_stamps[2048][16];
 #define MM_STAMP(k) do { if (tid == 0 && blockIdx.x < 2048) g_mm_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
@@ -1521,57 +1489,40 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define SRK_MM_SLOTS 8  // tiles per multiplying wave
 #define SRK_MM_LDW 208  // row stride of the round buffers (doubles): 13 tiles of 16 columns
 typedef double srk_double4 __attribute__((ext_vector_type(4)));
-// the K = 4 steps of one round for a wave with NS tiles: operands of all tiles first, then the MFMAs (branch-free).
-// P0 / P1: operand pattern of the wave's tiles 0 .. 3 / 4 .. 7 (the two half steps of a K step):
-//   0   every tile with its own A (row) and B (column) operand: 8 LDS reads per 4 MFMAs;
-//   4   the four tiles lie in ONE tile row: one A serves them (5 reads);
-//   13, 22, 31   the first 1 / 2 / 3 tiles lie in one tile row, the others in a second one: two A operands (6 reads).
-// tools/ubench/mfma64_lds.hip: an LDS-fed fp64 MFMA stream issues an MFMA every ~88 cycles with one operand pair per
-// MFMA and every ~73 when an operand serves two -- the reads, not their latency, are what the stream waits for.
-template <int NS, int P0, int P1>
+// the K = 4 steps of one round for a wave whose tiles are anywhere in the grid (frame sets smaller than the full 13 x 13 tile
+// grid: tiles dealt out row-major): every tile with its own A (row) and B (column) operand, in half steps of four tiles.  The
+// operand addresses (lane part + wave-uniform tile offset) are formed again at every half step -- opaque to the compiler, which
+// would otherwise keep all 16 of them in VGPRs -- so that a second operand set fits the 128 registers: the next half step's LDS
+// reads are in flight while this one's four MFMAs issue.
 __device__ __forceinline__ void schur_mm_steps(srk_double4 (&acc)[SRK_MM_SLOTS], const double* bw, const double* by,
                                                const int (&ta)[SRK_MM_SLOTS], const int (&tb)[SRK_MM_SLOTS], int lbase)
 {
-    static_assert(NS == 8, "two half steps of four tiles");
-    // half step hs = (K step hs / 2, tiles 4 (hs & 1) .. + 3).  The operand addresses (lane part + wave-uniform tile
-    // offset) are formed again at every half step -- opaque to the compiler, which would otherwise keep all 16 of them
-    // in VGPRs -- so that a second operand set fits the 128 registers: the next half step's LDS reads are in flight
-    // while this one's four MFMAs issue.
-    auto load = [&](double (&a)[4], double (&b)[4], int hs, auto pc) {
-        constexpr int P = decltype(pc)::value;
+    static_assert(SRK_MM_SLOTS == 8, "two half steps of four tiles");
+    // half step hs = (K step hs / 2, tiles 4 (hs & 1) .. + 3)
+    auto load = [&](double (&a)[4], double (&b)[4], int hs) {
         int lb = lbase;
         asm volatile("" : "+v"(lb));
         const int ko = (hs >> 1) * 4 * SRK_MM_LDW, s0 = (hs & 1) * 4;
-        if constexpr (P == 0) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = bw[ko + lb + ta[s0 + s]];
-        } else {
-            a[0] = bw[ko + lb + ta[s0]];
-            if constexpr (P != 4) a[3] = bw[ko + lb + ta[s0 + 3]];
-        }
+        for (int s = 0; s < 4; ++s) a[s] = bw[ko + lb + ta[s0 + s]];
 #pragma unroll
         for (int s = 0; s < 4; ++s) b[s] = by[ko + lb + tb[s0 + s]];
     };
-    auto mac = [&](const double (&a)[4], const double (&b)[4], int hs, auto pc) {
-        constexpr int P = decltype(pc)::value;
-        constexpr int NF = P == 0 ? 0 : (P == 4 ? 4 : P / 10); // tiles of the half step in its first tile row
+    auto mac = [&](const double (&a)[4], const double (&b)[4], int hs) {
         const int s0 = (hs & 1) * 4;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(P == 0 ? a[s] : (s < NF ? a[0] : a[3]), b[s], acc[s0 + s], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) acc[s0 + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc[s0 + s], 0, 0, 0);
     };
-    using C0 = std::integral_constant<int, P0>;
-    using C1 = std::integral_constant<int, P1>;
-    // always the three K steps of a full round: in a short last round the k rows of the missing landmarks are zeros
-    // (y_round), and one code path keeps the accumulators in place
+    // always the three K steps of a full round: in a short last round the k rows of the missing landmarks are zeros, and one
+    // code path keeps the accumulators in place
     double a0[4], b0[4], a1[4], b1[4];
-    load(a0, b0, 0, C0{});
-    load(a1, b1, 1, C1{}); mac(a0, b0, 0, C0{});
-    load(a0, b0, 2, C0{}); mac(a1, b1, 1, C1{});
-    load(a1, b1, 3, C1{}); mac(a0, b0, 2, C0{});
-    load(a0, b0, 4, C0{}); mac(a1, b1, 3, C1{});
-    load(a1, b1, 5, C1{}); mac(a0, b0, 4, C0{});
-    mac(a1, b1, 5, C1{});
+    load(a0, b0, 0);
+    load(a1, b1, 1); mac(a0, b0, 0);
+    load(a0, b0, 2); mac(a1, b1, 1);
+    load(a1, b1, 3); mac(a0, b0, 2);
+    load(a0, b0, 4); mac(a1, b1, 3);
+    load(a1, b1, 5); mac(a0, b0, 4);
+    mac(a1, b1, 5);
 }
 // the same for a wave whose eight tiles are a 2 x 4 BLOCK of the tile grid (tiles 0 .. 3: row ta[0], columns tb[0 .. 3];
 // tiles 4 .. 7: row ta[4], the same columns): two A and four B operands serve the eight MFMAs of a K step -- 6 LDS reads
@@ -1675,10 +1626,23 @@ __device__ __forceinline__ void schur_mm_steps_row(srk_double4 (&acc)[SRK_MM_SLO
     load(o0, 2); mac(o1);
     mac(o0);
 }
-// KIND 0: every run of the scene is uniform (all its landmarks see the same frames: the bench scenes) -- SYRK form, double
-// rounds; KIND 1: the scene has runs over the UNION of different frame lists -- W + Y form with masks, which serves a uniform
-// run as well (full masks), so a scene with both kinds (the dino stand-in) is ONE launch, not two latency-bound ones.  Two
-// instantiations, two register allocations (together: 30 spilled registers); the host picks by what the scene holds.
+// KIND 0: every run of the scene is uniform (all its landmarks see the same frames: the bench scenes); KIND 1: the scene has
+// runs over the UNION of different frame lists (ragged feature tracks) -- a cell (landmark, frame slot) the landmark does not
+// see is staged as a block of zeros; a uniform run is the full-mask case of that, so a scene with both kinds (the dino
+// stand-in) is ONE launch.  Both kinds (and both storage precisions of W's 21 factors) take
+// the SYRK form: with E = L L^T the sum W^T E^-1 W is Z^T Z, Z = L^-1 W -- ONE staged array, both MFMA operands read it.
+// (Round 3 retired the W + Y form: W and Y = E^-1 W staged side by side, Y formed by a second pass over the staged W.)
+//
+// Roles.  12 multiplying waves own the <= 91 16 x 16 tiles on and below the diagonal of the 13 x 13 tile grid (8 tile slots = 64
+// accumulator registers a wave); 4 helper waves stage Z: helper lane (m, cell) forms ROW m (point coordinate) of the cell's
+// observation -- z[m][:] = (L^-1 Ap)[m] Af[:] + (L^-1 Bp)[m] Bf[:] from the 21 factors, two multiply-adds per entry -- and writes it as five 16-byte LDS stores; the right-hand side term Z^T (L^-1 g) accumulates
+// in its registers.  The arena holds six rounds of four landmarks (round u in buffer u % 6); a barrier closes a DOUBLE round:
+// rounds r, r + 1 are multiplied (six K = 4 steps a wave) while the helpers stage r + 2 (loads issued half a double round
+// ago) and r + 3.  Rounds 0 and 1 are staged by the whole workgroup in the prologue, behind one barrier.  The flush adds every
+// accumulator entry on or below the diagonal of the sum to S with fp64 atomics, straight from the registers.
+// What was measured on the way (DESIGN sections 5 and 8): the helpers' instructions do not overlap with the MFMA streams of
+// their SIMD, so what counts is how FEW instructions both sides issue; latency hiding on the helper side, barrier-free
+// progress words, leaner block-wave address arithmetic each made it slower.
 template <typename WT, int KIND>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
@@ -1690,20 +1654,24 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     constexpr int PB = SRK_GRP_PB;             // landmarks of a round
     constexpr int KR = 3 * PB;                 // k rows of a round
     constexpr int LDW = SRK_MM_LDW;            // row stride (doubles)
-    constexpr int WB = KR * LDW;               // one buffer: W or Y of a round
-    constexpr int CAP = 6 * WB;                // KIND 1: W0 | W1 | W2 | Y0 | Y1; KIND 0: six rounds of Z (round u in buffer u % 6)
-    constexpr int QMAX = PB * SRK_WS_NF;       // observations of a round
+    constexpr int WB = KR * LDW;               // one round of Z
+    constexpr int CAP = 6 * WB;                // six rounds (round u in buffer u % 6)
+    constexpr int QMAX = PB * SRK_WS_NF;       // cells (landmark, frame slot) of a round
     constexpr int NH = SRK_MM_THREADS - 64 * SRK_MM_CW; // helper lanes
+    constexpr bool masked = KIND == 1;
+    constexpr int NV = SRK_WF_PLANES; // values of an observation a row lane keeps in flight: its 21 factors
     static_assert(SRK_WS_NF * 10 <= LDW && KR % 4 == 0, "round buffers");
     static_assert(SRK_MM_CW * SRK_MM_SLOTS >= 13 * 14 / 2, "tiles do not fit the multiplying waves");
     static_assert((SRK_GRP_MAXPTS + PB - 1) / PB < 64, "a run's row_ptr entries do not fit a wave");
+    static_assert(3 * QMAX <= NH && 2 * 3 * QMAX <= SRK_MM_THREADS, "row lanes");
+    (void)obs_pt; (void)obs_slot;
     __shared__ __attribute__((aligned(16))) double sBuf[CAP];
-    __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12];
+    __shared__ __attribute__((aligned(16))) double sE[SRK_GRP_MAXPTS][12]; // lower triangle of L^-1 by rows | L^-1 g
     __shared__ double sRhs[SRK_WS_NF * 10];
     __shared__ int32_t sVar[SRK_WS_NF * 10]; // row / column of S of the sum's row / column e; -1: a gauge-fixed variable
-    // KIND 1, fp64 factors: first observation (relative to the run's) and frame-slot mask of every landmark of the run
-    __shared__ int32_t sOff[KIND == 1 ? SRK_GRP_MAXPTS : 1];
-    __shared__ uint32_t sMask[KIND == 1 ? SRK_GRP_MAXPTS : 1];
+    // KIND 1: first observation (relative to the run's) and frame-slot mask of every landmark of the run
+    __shared__ int32_t sOff[masked ? SRK_GRP_MAXPTS : 1];
+    __shared__ uint32_t sMask[masked ? SRK_GRP_MAXPTS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef SRK_MM_STAMPS
     if (tid == 64 * SRK_MM_CW && blockIdx.x < 2048) for (int k = 10; k < 16; ++k) g_mm_stamps[blockIdx.x][k] = 0;
@@ -1723,10 +1691,6 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int64_t p0 = grp_first[blockIdx.x];
     const int np = grp_count[blockIdx.x];
     const int nfu = grp_nf[blockIdx.x];
-    // fp64 factor storage: both kinds take the SYRK form (`masked`: KIND 1, a cell (landmark, frame slot) the landmark does not
-    // see is staged as zeros); `ragged` = the W + Y form with masks, left for the opt-in float storage of W
-    constexpr bool masked = KIND == 1 && WStore<WT>::factored;
-    constexpr bool ragged = KIND == 1 && !WStore<WT>::factored;
     if (KIND == 0 && nfu < 0) return; // (never launched on such a scene)
     const int nf = nfu < 0 ? -nfu : nfu;
     if (nf > SRK_WS_NF) return; // k_schur_grouped takes the wider runs
@@ -1738,11 +1702,9 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     const int R = (np + PB - 1) / PB;
     const int nf10 = nf * 10;
     const int64_t o0 = row_ptr[p0];
-    // LDS column of observation (staged landmark pl, frame slot a), W row k = 10 m + r:  (3 pl + m) LDW + 10 a + r
-    // rounds 0 and 1 are staged by the whole workgroup, their loads in flight together with the 3x3 blocks' below
-    constexpr bool rows01 = WStore<WT>::factored; // rounds 0 and 1 staged as Z rows here (below)
-    // (masked) the cell (landmark pl of round rd, frame slot a): which observation, if any.  Runs over the UNION of their
-    // landmarks' frame lists: a landmark's observations are its mask's set bits in slot order.
+    // LDS column of cell (staged landmark pl, frame slot a), Z row k = 3 pl + m:  (3 pl + m) LDW + 10 a + i
+    // (masked) the cell (landmark pidx of the run, frame slot a): which observation, if any -- a landmark's observations are
+    // its mask's set bits in slot order
     auto cell_obs = [&](int pidx, int a, bool& seen) -> unsigned {
         seen = false;
         if (pidx >= np) return 0u;
@@ -1757,31 +1719,49 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         }
         __syncthreads();
     }
-    if constexpr (rows01) {
-        // fp64 factors, uniform runs: thread (rd, sm, sq) of the first 2 * 3 * QMAX takes row sm of observation sq of round
-        // rd, like the helpers' stage_round2 -- its 21 factor loads are in flight together with the 3x3 blocks' loads, Z leaves
-        // after ONE barrier (the raw-W pass and the helpers' in-place L^-1 pass that this replaces cost a workgroup ~9.7 us
-        // before its first MFMA; this ~4)
-        static_assert(2 * 3 * QMAX <= SRK_MM_THREADS, "prologue row threads");
-        const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
+    // what a row of an observation's Z needs from memory: the 21 factors (every plane base wave-uniform, one 32-bit lane offset
+    // for all loads; float storage widens here)
+    auto load_src = [&](double (&v)[NV], unsigned voff) {
+#pragma unroll
+        for (int k = 0; k < SRK_WF_PLANES; ++k) v[k] = (double)(W + (int64_t)k * d.Os)[voff];
+    };
+    // row m of Z = L^-1 W from those values and the landmark's sE row E; returns hm = (L^-1 g)[m]
+    auto z_row = [&](const double (&v)[NV], const double* E, int m, double (&z)[10]) -> double {
+        const int r3 = m * (m + 1) / 2; // row m of the lower triangle of L^-1: 1, 2 or 3 entries
+        const double li0 = E[r3], li1 = m >= 1 ? E[r3 + 1] : 0.0, li2 = m >= 2 ? E[r3 + 2] : 0.0;
+        const double am = li0 * v[SRK_WF_AP] + li1 * v[SRK_WF_AP + 1] + li2 * v[SRK_WF_AP + 2];
+        const double bm = li0 * v[SRK_WF_BP] + li1 * v[SRK_WF_BP + 1] + li2 * v[SRK_WF_BP + 2];
+        z[0] = am * v[SRK_WF_AF0];
+        z[1] = bm * v[SRK_WF_BF1];
+        z[2] = am * v[SRK_WF_G];
+        z[3] = bm * v[SRK_WF_G];
+#pragma unroll
+        for (int i = 4; i < 10; ++i) z[i] = am * v[SRK_WF_AF4 + i - 4] + bm * v[SRK_WF_BF4 + i - 4];
+        return E[6 + m];
+    };
+    {
+        // ---- prologue: rounds 0 and 1 by the whole workgroup.  Thread (rd, sm, sq) of the first 2 * 3 * QMAX takes row sm of
+        // cell sq of round rd -- its loads are in flight together with the 3x3 blocks' loads, Z leaves after ONE barrier
         const int rd = tid / (3 * QMAX), rem = tid - rd * (3 * QMAX);
         const int sm = rem / QMAX, sq = rem - sm * QMAX;
-        const int oa = rd ? o1 : 0, nq = rd < 2 ? (rd ? o2 - o1 : o1) : 0;
-        bool row_on = sq < nq;
-        bool cell = false; // (masked) a cell of the round's (landmark, slot) grid: written in any case, zeros when not seen
-        unsigned voff = (unsigned)(o0 + oa + sq);
+        const int pl = sq / nf, a = sq - pl * nf;
+        bool row_on = false, cell = false; // cell: written in any case (zeros when the landmark does not see the frame)
+        unsigned voff = 0;
         if constexpr (masked) {
-            const int pl = sq / nf, a = sq - pl * nf;
             cell = rd < 2 && pl < PB;
-            row_on = false;
             if (cell) voff = cell_obs(rd * PB + pl, a, row_on);
+        } else if (rd < 2) {
+            const int la = rd * PB < np ? rd * PB : np, lb = (rd + 1) * PB < np ? (rd + 1) * PB : np;
+            const int oa = (int)(row_ptr[p0 + la] - o0), nq = (int)(row_ptr[p0 + lb] - o0) - oa;
+            row_on = sq < nq;
+            voff = (unsigned)(o0 + oa + sq);
         }
-        double f[SRK_WF_PLANES];
-        if (row_on) {
-#pragma unroll
-            for (int k = 0; k < SRK_WF_PLANES; ++k) f[k] = (W + (int64_t)k * d.Os)[voff];
-        }
+        double v[NV];
+        if (row_on) load_src(v, voff);
         if (tid < np) {
+            // E = L L^T.  A skipped landmark (|det| <= 1e-12, :1877-1881) stages zeros; one whose block passes that check but has
+            // no positive pivots stages zeros as well and is handed back (irr) to the per-landmark inverse path, which
+            // k_assemble's tail workgroups run.
             double Lc[6], hh[3];
             const int st = point_block_cholesky(Vg, d.Ns, p0 + tid, c, Lc, hh);
 #pragma unroll
@@ -1791,431 +1771,111 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             if (st == 2) irr[1 + atomicAdd(&irr[0], 1)] = (int32_t)(p0 + tid);
         }
         __syncthreads(); // sE; sRhs is zeroed
+        double2* wp = reinterpret_cast<double2*>(sBuf + rd * WB + (3 * pl + sm) * LDW + 10 * a);
         if (row_on) {
-            const int pl = sq / nf, a = sq - pl * nf;
-            const double* E = sE[rd * PB + pl];
-            const int r3 = sm * (sm + 1) / 2;
-            const double li0 = E[r3], li1 = sm >= 1 ? E[r3 + 1] : 0.0, li2 = sm >= 2 ? E[r3 + 2] : 0.0, hm = E[6 + sm];
-            const double am = li0 * f[SRK_WF_AP] + li1 * f[SRK_WF_AP + 1] + li2 * f[SRK_WF_AP + 2];
-            const double bm = li0 * f[SRK_WF_BP] + li1 * f[SRK_WF_BP + 1] + li2 * f[SRK_WF_BP + 2];
             double z[10];
-            z[0] = am * f[SRK_WF_AF0];
-            z[1] = bm * f[SRK_WF_BF1];
-            z[2] = am * f[SRK_WF_G];
-            z[3] = bm * f[SRK_WF_G];
-#pragma unroll
-            for (int i = 4; i < 10; ++i) z[i] = am * f[SRK_WF_AF4 + i - 4] + bm * f[SRK_WF_BF4 + i - 4];
-            double2* wp = reinterpret_cast<double2*>(sBuf + rd * WB + (3 * pl + sm) * LDW + 10 * a);
+            const double hm = z_row(v, sE[rd * PB + pl], sm, z);
 #pragma unroll
             for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
 #pragma unroll
             for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], z[i] * hm);
         } else if (masked && cell) {
-            const int pl = sq / nf, a = sq - pl * nf;
-            double2* wp = reinterpret_cast<double2*>(sBuf + rd * WB + (3 * pl + sm) * LDW + 10 * a);
 #pragma unroll
             for (int i = 0; i < 5; ++i) wp[i] = make_double2(0.0, 0.0);
         }
-    } else {
-        const int o1 = (int)(row_ptr[p0 + (np < PB ? np : PB)] - o0), o2 = (int)(row_ptr[p0 + (np < 2 * PB ? np : 2 * PB)] - o0);
-        constexpr int NI = (2 * 30 * QMAX + SRK_MM_THREADS - 1) / SRK_MM_THREADS;
-        double v[NI];
-        int dst[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int e = tid + SRK_MM_THREADS * j;
-            const int rd = e / (30 * QMAX), rem = e - rd * (30 * QMAX);
-            const int k = rem / QMAX, q = rem - k * QMAX;
-            const int oa = rd ? o1 : 0, nq = rd ? o2 - o1 : o1;
-            dst[j] = -1;
-            v[j] = 0;
-            if (rd < 2 && q < nq) {
-                v[j] = w_entry<WT>(W, d.Os, o0 + oa + q, k);
-                int pl, a;
-                if (ragged) { pl = obs_pt[o0 + oa + q] - (int)(p0 + rd * PB); a = (int)obs_slot[o0 + oa + q]; }
-                else { pl = q / nf; a = q - pl * nf; }
-                const int m = k / 10, rr = k - 10 * m;
-                dst[j] = rd * WB + (3 * pl + m) * LDW + 10 * a + rr;
-            }
-        }
-        if (tid < np && ragged) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
-            double Einv[9], g[3];
-            bool ok = point_block_inverse(Vg, d.Ns, p0 + tid, c, Einv, g);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sE[tid][k] = ok ? Einv[k] : 0.0;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-                sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
-        }
-        if (tid < np && !ragged) {
-            // uniform runs take the SYRK form: E = L L^T, the helpers stage Z = L^-1 W alone and both MFMA operands read
-            // it (sum W^T E^-1 W = Z^T Z).  sE row: the lower triangle of L^-1 by rows | L^-1 g.  A skipped landmark (|det| <=
-            // 1e-12) stages zeros; one whose block passes that check but has no positive pivots stages zeros as well and is
-            // handed back (irr) to the per-landmark inverse path, which k_assemble's tail workgroups run.
-            double Lc[6], hh[3];
-            const int st = point_block_cholesky(Vg, d.Ns, p0 + tid, c, Lc, hh);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) sE[tid][k] = st == 1 ? Lc[k] : 0.0;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) sE[tid][6 + m] = st == 1 ? hh[m] : 0.0;
-            if (st == 2) irr[1 + atomicAdd(&irr[0], 1)] = (int32_t)(p0 + tid);
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-            if (dst[j] >= 0) sBuf[dst[j]] = v[j];
     }
     const int nt = (nf10 + 15) >> 4; // tile rows of the sum
-    __syncthreads(); // sE, sVar, sRhs and W of rounds 0 and 1 are visible
+    __syncthreads(); // sE, sVar, sRhs and Z of rounds 0 and 1 are visible
     MM_STAMP(1);
-    // two roles, two code paths, one barrier sequence (1 + R for the rounds, two per flush pass)
+    // two roles, two code paths, one barrier sequence (one, then one per double round, one at the end)
     if (wv >= SRK_MM_CW) {
-        // ---- helpers: lane h of 256
+        // ---- helpers: lane h of 256 = QMAX m + cell
         const int h = tid - 64 * SRK_MM_CW;
         __builtin_amdgcn_s_setprio(2); // their few instructions must not queue behind the MFMA streams (round 3, measured:
                                        // without it the Schur phase takes 462 instead of 432-443 us, with the multiplying
                                        // waves raised above the helpers 460)
         const int rel = (int)(row_ptr[p0 + (lane * PB < np ? lane * PB : np)] - o0); // lane r: first observation of round r
-        // staging: lane h = QMAX sm + sq moves the ten W rows k = 10 sm .. 10 sm + 9 (point coordinate sm) of observation
-        // sq of the round: ten loads coalesced over sq, ten consecutive doubles of one LDS row
-        static_assert(3 * QMAX <= NH, "staging lanes");
+        // Why rows (round 3): in-kernel stamps had the multiplying waves through a round's MFMAs after 2.0 us and then 1.3 us at
+        // the barrier -- waiting for the HELPERS, whose vector-ALU instructions only issue in the gaps of their SIMD's three MFMA
+        // streams (tools/ubench/mfma64_side.hip): what a round costs them is their instruction count.  A lane per COLUMN class
+        // (the three coordinates of four columns) needed ~90 vector-ALU instructions a round; a row needs three multiply-adds
+        // for its two scalars and two for each of its ten entries, and its ten entries leave as five 16-byte LDS writes: ~40.
         const int sm = h / QMAX, sq = h - sm * QMAX;
-        double pre[10];
-        double fpre[2 + SRK_WF_PLANES - SRK_WF_AF0]; // (fp64 storage) Ap[sm], Bp[sm], then planes SRK_WF_AF0 .. of the observation
-        int sdst, nq_pre = 0;
-        {
-            const int pl = sq / nf, a = sq - pl * nf; // uniform runs: landmark q / nf, slot q % nf
-            sdst = (3 * pl + sm) * LDW + 10 * a;
+        const int pl = sq / nf, a = sq - pl * nf;
+        const int dst = (3 * pl + sm) * LDW + 10 * a;
+        double v[NV], racc[10];
+        bool row_on = false, cell = false;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) racc[i] = 0;
+        auto load_round = [&](int r) { // global loads of round r (left in flight)
+            unsigned voff;
+            if constexpr (masked) {
+                cell = sm < 3 && pl < PB;
+                row_on = false;
+                voff = cell ? cell_obs(r * PB + pl, a, row_on) : 0u;
+            } else {
+                const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
+                row_on = sm < 3 && sq < rb - ra;
+                voff = (unsigned)(o0 + ra + sq);
+            }
+            if (row_on) load_src(v, voff);
+        };
+        auto stage_round = [&](int r, double* bw) {
+            const int pb = r * PB;
+            const int nb = np - pb < PB ? np - pb : PB;
+            double2* wp = reinterpret_cast<double2*>(bw + dst); // (3 pl + m) LDW + 10 a: 16-byte aligned
+            if (row_on) {
+                double z[10];
+                const double hm = z_row(v, sE[pb + pl], sm, z);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) racc[i] = fma(z[i], hm, racc[i]);
+            } else if (masked && cell) { // the landmark does not see this frame (or the round is short): a block of zeros
+#pragma unroll
+                for (int i = 0; i < 5; ++i) wp[i] = make_double2(0.0, 0.0);
+            }
+            // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
+            if (nb < PB)
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
+        };
+        for (int u = 0; u < 2 && u < R; ++u) { // short rounds among the prologue's
+            const int nb = np - u * PB < PB ? np - u * PB : PB;
+            if (nb < PB)
+                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) sBuf[u * WB + 3 * nb * LDW + t] = 0;
         }
-        auto load_round = [&](int r) { // global loads of round r into `pre` (left in flight)
-            const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
-            nq_pre = sm < 3 ? rb - ra : 0;
-            if (sq < nq_pre) {
-                if constexpr (WStore<WT>::factored) {
-                    // fp64 storage: the raw factors stay in flight -- the lane's two point-side factors (plane offset sm Os in
-                    // the lane part of the address, wave-uniform plane bases) and the 15 frame-side ones
-                    const unsigned voff = (unsigned)(o0 + ra + sq), vrow = voff + (unsigned)sm * (unsigned)d.Os;
-                    fpre[0] = (W + (int64_t)SRK_WF_AP * d.Os)[vrow];
-                    fpre[1] = (W + (int64_t)SRK_WF_BP * d.Os)[vrow];
-#pragma unroll
-                    for (int k = SRK_WF_AF0; k < SRK_WF_PLANES; ++k) fpre[2 + k - SRK_WF_AF0] = (W + (int64_t)k * d.Os)[voff];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) pre[i] = w_entry<WT>(W, d.Os, o0 + ra + sq, 10 * sm + i);
-                }
-                if (ragged)
-                    sdst = (3 * (obs_pt[o0 + ra + sq] - (int)(p0 + r * PB)) + sm) * LDW + 10 * (int)obs_slot[o0 + ra + sq];
-            }
-        };
-        auto stage_round = [&](double* bw) { // `pre` -> W in LDS
-            if (sq < nq_pre) {
-                if constexpr (WStore<WT>::factored) {
-                    const double ap = fpre[0], bp = fpre[1], gq = fpre[2 + SRK_WF_G - SRK_WF_AF0];
-                    double w[10];
-                    w[0] = ap * fpre[2];
-                    w[1] = bp * fpre[2 + SRK_WF_BF1 - SRK_WF_AF0];
-                    w[2] = ap * gq;
-                    w[3] = bp * gq;
-#pragma unroll
-                    for (int i = 4; i < 10; ++i)
-                        w[i] = ap * fpre[2 + SRK_WF_AF4 - SRK_WF_AF0 + i - 4] + bp * fpre[2 + SRK_WF_BF4 - SRK_WF_AF0 + i - 4];
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) bw[sdst + i] = w[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) bw[sdst + i] = pre[i];
-                }
-            }
-        };
-        // Y = E^-1 W: helper wave ypl forms the rows of staged landmark ypl, its lanes take the columns lane + 64 i, and
-        // keep the rhs term W^T (E^-1 g) of those columns (the PB waves' shares meet in sRhs at the end)
-        static_assert(NH == 64 * PB, "one helper wave per staged landmark");
-        constexpr int NC = (SRK_WS_NF * 10 + 63) / 64;
-        const int ypl = __builtin_amdgcn_readfirstlane(h >> 6);
-        double racc[NC];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) racc[i] = 0;
-        uint32_t mask_pre = 0; // ragged runs: the frame slots this wave's landmark of the NEXT Y round sees
-        auto load_mask = [&](int r) { if (ragged && r * PB + ypl < np) mask_pre = pt_mask[p0 + r * PB + ypl]; };
-        auto y_round = [&](int r, double* bw, double* by) { // Y of round r from its staged W
-            const int pb = r * PB;
-            const int nb = np - pb < PB ? np - pb : PB;
-            if (ypl < nb) {
-                // straight-line code: every lane loads and stores (a lane past the last column works on the padding
-                // column LDW - 1, which no flushed entry depends on) -- per-element branches made this a chain of nine
-                // LDS round trips, 1.7 us a round
-                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]); // rows are 96 B: 16-byte aligned
-                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4], eab = E2[5];
-                double w[NC][3];
-                int cc[NC];
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const int col = lane + 64 * i;
-                    cc[i] = col < nf10 ? col : LDW - 1;
-                    const double* wp = bw + 3 * ypl * LDW + cc[i];
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) w[i][m] = wp[m * LDW];
-                }
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const int col = lane + 64 * i;
-                    double* wp = bw + 3 * ypl * LDW + cc[i];
-                    double* yp = by + 3 * ypl * LDW + cc[i];
-                    double w0 = w[i][0], w1 = w[i][1], w2 = w[i][2];
-                    if (ragged) { // a frame the landmark misses: zero blocks instead of the earlier round's stale W
-                        const bool on = (mask_pre >> (col / 10)) & 1u;
-                        w0 = on ? w0 : 0.0; w1 = on ? w1 : 0.0; w2 = on ? w2 : 0.0;
-                        wp[0] = w0; wp[LDW] = w1; wp[2 * LDW] = w2;
-                    }
-                    yp[0] = e01.x * w0 + e01.y * w1 + e23.x * w2;
-                    yp[LDW] = e23.y * w0 + e45.x * w1 + e45.y * w2;
-                    yp[2 * LDW] = e67.x * w0 + e67.y * w1 + e89.x * w2;
-                    const double rr = w0 * e89.y + w1 * eab.x + w2 * eab.y;
-                    racc[i] += col < nf10 ? rr : 0.0;
-                }
-            }
-            // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
-            if (nb < PB)
-                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = by[3 * nb * LDW + t] = 0;
-        };
-        // uniform runs, rounds 0 and 1 (staged raw by the whole workgroup): Z = L^-1 W in place
-        auto z_round = [&](int r, double* bw) {
-            const int pb = r * PB;
-            const int nb = np - pb < PB ? np - pb : PB;
-            if (ypl < nb) {
-                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + ypl]);
-                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
-                const double I00 = e01.x, I10 = e01.y, I11 = e23.x, I20 = e23.y, I21 = e45.x, I22 = e45.y;
-                double w[NC][3];
-                int cc[NC];
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const int col = lane + 64 * i;
-                    cc[i] = col < nf10 ? col : LDW - 1;
-                    const double* wp = bw + 3 * ypl * LDW + cc[i];
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) w[i][m] = wp[m * LDW];
-                }
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const int col = lane + 64 * i;
-                    double* wp = bw + 3 * ypl * LDW + cc[i];
-                    const double z0 = I00 * w[i][0];
-                    const double z1 = I10 * w[i][0] + I11 * w[i][1];
-                    const double z2 = I20 * w[i][0] + I21 * w[i][1] + I22 * w[i][2];
-                    wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
-                    const double rr = z0 * e67.x + z1 * e67.y + z2 * e89.x;
-                    racc[i] += col < nf10 ? rr : 0.0;
-                }
-            }
-            if (nb < PB)
-                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
-        };
-        // Uniform runs (every landmark sees the run's whole frame set), rounds >= 2: W and Y of a round are staged TOGETHER,
-        // straight from the registers the global loads landed in.  In-kernel stamps of the two-pass form below (stage W,
-        // then read it back and form Y a round later): the helpers -- which only issue while their SIMD's multiplying
-        // waves are stalled -- spent 2.4 us a round in the Y pass, and the multiplying waves stood at the round barrier.
-        // Lane h = QMAX i0 + q takes observation q of the round and the frame variables i = i0, i0 + 3, i0 + 6 (, 9): all
-        // three point coordinates of a column are its own loads, so y = E^-1 w needs no LDS read-back, the landmark's E
-        // stays in registers for the lane's four columns, and W, Y leave as plain LDS writes.  Y is triple-buffered like W.
-        constexpr int NBT = 4; // column batches of a lane
-        const int q2 = h % QMAX, i02 = h / QMAX;
-        const int pl2 = q2 / nf, a2 = q2 - pl2 * nf;
-        const int dst2 = 3 * pl2 * LDW + 10 * a2;
-        double pre2[NBT][3], racc2[NBT];
-#pragma unroll
-        for (int b = 0; b < NBT; ++b) racc2[b] = 0;
-        int nq2 = 0;
-        // ---- fp64 storage (the rank-2 factors): lane h = QMAX m + q takes ROW m (point coordinate) of observation q,
-        //     z[m][:] = (L^-1 Ap)[m] Af[:] + (L^-1 Bp)[m] Bf[:],   (L^-1 Ap)[m] = row m of L^-1 (from sE) . Ap.
-        // Why rows: in-kernel stamps had the multiplying waves through a round's MFMAs after 2.0 us and then 1.3 us at the
-        // barrier -- waiting for the HELPERS, whose vector-ALU instructions only issue in the gaps of their SIMD's three MFMA
-        // streams (about one per MFMA slot, tools/ubench/mfma64_side.hip): what a round costs them is their instruction
-        // count.  The column split above (each lane the three coordinates of four columns) needed ~90 vector-ALU
-        // instructions a round -- the substitution for all three rows in every lane, 64-bit address arithmetic for its
-        // lane-dependent factor planes, twelve 8-byte LDS writes; a row needs three multiply-adds for its two scalars, two for
-        // each of its ten entries, every plane base is wave-uniform (one 32-bit lane offset for all 21 loads) and its ten
-        // entries leave as five 16-byte LDS writes: ~40.
-        const int sm3 = h / QMAX, sq3 = h - sm3 * QMAX;
-        const int pl3 = sq3 / nf, a3 = sq3 - pl3 * nf;
-        const int dst3 = (3 * pl3 + sm3) * LDW + 10 * a3;
-        double f3[SRK_WF_PLANES], racc3[10];
-        bool cell3 = false; // (masked) this lane owns a cell of the round in flight
-#pragma unroll
-        for (int i = 0; i < 10; ++i) racc3[i] = 0;
-        auto load_round2 = [&](int r) {
-            const int ra = __builtin_amdgcn_readlane(rel, r), rb = __builtin_amdgcn_readlane(rel, r + 1);
-            if constexpr (WStore<WT>::factored) {
-                unsigned voff = (unsigned)(o0 + ra + sq3);
-                if constexpr (masked) { // the cell (landmark pl3 of the round, slot a3): seen -> its observation, else zeros
-                    cell3 = sm3 < 3 && pl3 < PB;
-                    bool seen = false;
-                    if (cell3) voff = cell_obs(r * PB + pl3, a3, seen);
-                    nq2 = seen ? QMAX : 0; // (sq3 < nq2  <=>  seen)
-                } else {
-                    nq2 = sm3 < 3 ? rb - ra : 0;
-                }
-                if (sq3 < nq2) {
-#pragma unroll
-                    for (int k = 0; k < SRK_WF_PLANES; ++k) {
-                        const WT* sb = W + (int64_t)k * d.Os; // wave-uniform plane base
-                        f3[k] = sb[voff];
-                    }
-                }
-            } else {
-            nq2 = i02 < 3 ? rb - ra : 0;
-            if (q2 < nq2) {
-                // plane base (wave-uniform: scalar registers) + one 32-bit lane offset: no 64-bit address arithmetic per load
-                const unsigned voff = (unsigned)(o0 + ra + q2) + (unsigned)i02 * (unsigned)d.Os;
-#pragma unroll
-                for (int b = 0; b < NBT; ++b) {
-                    if (i02 + 3 * b < 10) {
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) {
-                            const WT* sb = W + (int64_t)(10 * m + 3 * b) * d.Os;
-                            pre2[b][m] = sb[voff];
-                        }
-                    }
-                }
-            }
-            }
-        };
-        // (round 3: the SYRK form -- Z = L^-1 W is the ONE staged array: half the LDS writes of the W + Y form)
-        auto stage_round2 = [&](int r, double* bw) {
-            const int pb = r * PB;
-            const int nb = np - pb < PB ? np - pb : PB;
-            if constexpr (WStore<WT>::factored) {
-                if (sq3 < nq2) {
-                    const double* E = sE[pb + pl3];
-                    const int r3 = sm3 * (sm3 + 1) / 2; // row sm3 of the lower triangle of L^-1: 1, 2 or 3 entries
-                    const double li0 = E[r3], li1 = sm3 >= 1 ? E[r3 + 1] : 0.0, li2 = sm3 >= 2 ? E[r3 + 2] : 0.0, hm = E[6 + sm3];
-                    const double am = li0 * f3[SRK_WF_AP] + li1 * f3[SRK_WF_AP + 1] + li2 * f3[SRK_WF_AP + 2];
-                    const double bm = li0 * f3[SRK_WF_BP] + li1 * f3[SRK_WF_BP + 1] + li2 * f3[SRK_WF_BP + 2];
-                    double z[10];
-                    z[0] = am * f3[SRK_WF_AF0];
-                    z[1] = bm * f3[SRK_WF_BF1];
-                    z[2] = am * f3[SRK_WF_G];
-                    z[3] = bm * f3[SRK_WF_G];
-#pragma unroll
-                    for (int i = 4; i < 10; ++i) z[i] = am * f3[SRK_WF_AF4 + i - 4] + bm * f3[SRK_WF_BF4 + i - 4];
-                    double2* wp = reinterpret_cast<double2*>(bw + dst3); // (3 pl + m) LDW + 10 a: 16-byte aligned
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) racc3[i] = fma(z[i], hm, racc3[i]);
-                } else if (masked && cell3) { // the landmark does not see this frame (or the round is short): a block of zeros
-                    double2* wp = reinterpret_cast<double2*>(bw + dst3);
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) wp[i] = make_double2(0.0, 0.0);
-                }
-            } else {
-            if (q2 < nq2) {
-                const double2* E2 = reinterpret_cast<const double2*>(sE[pb + pl2]);
-                const double2 e01 = E2[0], e23 = E2[1], e45 = E2[2], e67 = E2[3], e89 = E2[4];
-                const double I00 = e01.x, I10 = e01.y, I11 = e23.x, I20 = e23.y, I21 = e45.x, I22 = e45.y;
-#pragma unroll
-                for (int b = 0; b < NBT; ++b) {
-                    const int i = i02 + 3 * b;
-                    if (i < 10) {
-                        const double z0 = I00 * pre2[b][0];
-                        const double z1 = I10 * pre2[b][0] + I11 * pre2[b][1];
-                        const double z2 = I20 * pre2[b][0] + I21 * pre2[b][1] + I22 * pre2[b][2];
-                        double* wp = bw + dst2 + i;
-                        wp[0] = z0; wp[LDW] = z1; wp[2 * LDW] = z2;
-                        racc2[b] += z0 * e67.x + z1 * e67.y + z2 * e89.x;
-                    }
-                }
-            }
-            }
-            // a short last round: the k rows of the landmarks it does not have must not carry an earlier round's data
-            if (nb < PB)
-                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
-        };
-        load_mask(0);
-        auto zero_tail = [&](int r, double* bw) { // a short round: the k rows of the landmarks it does not have
-            const int nb = np - r * PB < PB ? np - r * PB : PB;
-            if (nb < PB)
-                for (int t = h; t < (KR - 3 * nb) * LDW; t += NH) bw[3 * nb * LDW + t] = 0;
-        };
-        if (ragged) y_round(0, sBuf, sBuf + 3 * WB);
-        else if (rows01) zero_tail(0, sBuf);
-        else z_round(0, sBuf);
-        load_mask(1);
-        if (!ragged) {
-            if (R > 1) { if (rows01) zero_tail(1, sBuf + WB); else z_round(1, sBuf + WB); }
-#pragma unroll
-            for (int i = 0; i < NC; ++i) { // the two-pass rounds' share of the rhs: out of the registers before the loop
-                if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
-                racc[i] = 0;
-            }
-            if (R > 2) load_round2(2);
-        } else if (R > 2) load_round(2);
-        lds_barrier(); // Y of round 0 is visible
+        if (R > 2) load_round(2);
+        lds_barrier(); // (the multiplying waves' first barrier)
 #ifdef SRK_MM_STAMPS
         tacc = wall_clock64();
 #endif
-        int wi = 2; // W buffer of round r + 2
-        if (!ragged) {
-            // (round 3) DOUBLE rounds: with Z alone in LDS the arena holds six rounds, so a barrier closes TWO rounds of four
-            // landmarks (six K = 4 steps of the multiplying waves) -- half the barriers, half the pipeline ramps.  Rounds r,
-            // r + 1 are multiplied while the helpers stage r + 2 (loads issued half a double round ago) and r + 3 (loads
-            // issued at the start of this one); round u lives in buffer u % 6.
-            for (int r = 0; r < R; r += 2) {
+        // DOUBLE rounds: a barrier closes two rounds of four landmarks (six K = 4 steps of the multiplying waves).  Rounds r,
+        // r + 1 are multiplied while the helpers stage r + 2 (loads issued half a double round ago) and r + 3 (loads issued at
+        // the start of this one).
+        for (int r = 0; r < R; r += 2) {
 #ifdef SRK_MM_NOHELP // ablation only (wrong results): the helpers stage nothing after the prologue -- what the MFMA streams take alone
-                if (d.N >= 0) { lds_barrier(); continue; }
+            if (d.N >= 0) { lds_barrier(); continue; }
 #endif
-                if (r + 2 < R) stage_round2(r + 2, sBuf + ((r + 2) % 6) * WB);
-#ifdef SRK_MM_STAMPS
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                MM_ACC(64 * SRK_MM_CW, 10, tacc);
-                if (r + 3 < R) {
-                    load_round2(r + 3);
-                    stage_round2(r + 3, sBuf + ((r + 3) % 6) * WB);
-                }
-                if (r + 4 < R) load_round2(r + 4);
-                MM_ACC(64 * SRK_MM_CW, 11, tacc);
-                lds_barrier(); // the products of rounds r, r + 1; Z of rounds r + 2, r + 3 are visible
-                MM_ACC(64 * SRK_MM_CW, 12, tacc);
-            }
-            if constexpr (WStore<WT>::factored) {
-                if (sm3 < 3 && pl3 < PB) {
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a3 + i], racc3[i]);
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < NBT; ++b)
-                    if (i02 < 3 && i02 + 3 * b < 10 && a2 < nf && pl2 < PB) atomicAdd(&sRhs[10 * a2 + i02 + 3 * b], racc2[b]);
-            }
-        } else
-        for (int r = 0; r < R; ++r) {
-            if (r + 2 < R) stage_round(sBuf + wi * WB);
+            if (r + 2 < R) stage_round(r + 2, sBuf + ((r + 2) % 6) * WB);
 #ifdef SRK_MM_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             MM_ACC(64 * SRK_MM_CW, 10, tacc);
-            if (r + 1 < R) {
-                const int w1 = wi == 0 ? 2 : wi - 1; // W buffer of round r + 1
-                y_round(r + 1, sBuf + w1 * WB, sBuf + (3 + ((r + 1) & 1)) * WB);
-                load_mask(r + 2);
+            if (r + 3 < R) {
+                load_round(r + 3);
+                stage_round(r + 3, sBuf + ((r + 3) % 6) * WB);
             }
-#ifdef SRK_MM_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            MM_ACC(64 * SRK_MM_CW, 13, tacc);
-            if (r + 3 < R) load_round(r + 3);
+            if (r + 4 < R) load_round(r + 4);
             MM_ACC(64 * SRK_MM_CW, 11, tacc);
-            wi = wi == 2 ? 0 : wi + 1;
-#ifndef SRK_MM_NO_ROUND_BARRIER // ablation only (results are wrong without it): what the per-round synchronisation costs
-            lds_barrier(); // the products of round r; W of round r + 2 and Y of round r + 1 are visible
-#endif
+            lds_barrier(); // the products of rounds r, r + 1; Z of rounds r + 2, r + 3 are visible
             MM_ACC(64 * SRK_MM_CW, 12, tacc);
         }
+        if (sm < 3 && pl < PB) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-            if (lane + 64 * i < nf10) atomicAdd(&sRhs[lane + 64 * i], racc[i]);
+            for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], racc[i]);
+        }
     } else {
-        // ---- multipliers: wave wv owns tiles u = wv + SRK_MM_CW s (row-major over (ti, tj <= ti)) of the nt x nt grid
+        // ---- multipliers: wave wv owns up to eight tiles of the nt x nt grid
         const int n_tiles = nt * (nt + 1) / 2;
         const int lr = lane & 15, lk = lane >> 4;
         // tile coordinates are wave-uniform: kept in scalar registers (readfirstlane), the lane part of an operand's
@@ -2223,12 +1883,11 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         const int wvu = __builtin_amdgcn_readfirstlane(wv);
         const int lbase = lk * LDW + lr;
         int ta[SRK_MM_SLOTS], tb[SRK_MM_SLOTS];
-        int ns = 0; // this wave's tiles
-        // The full-size grid (nt = 13: 20 frames, the bench scenes) of a uniform run is dealt out by the table
-        // srk_mm_tiles13: 2 x 4 blocks that share their operands (schur_mm_steps_blk), the rest as rows or single tiles.
-        // (uniform runs only: on ragged runs -- the helpers also mask and rewrite W there -- shared operands made the sum slower)
-        const bool runs = nt == 13 && !ragged, blk = runs && wvu < 9;
-        unsigned onmask = 0; // slots whose sum is flushed (a block's tile above the diagonal is computed, not flushed)
+        // The full-size grid (nt = 13: 20 frames, the bench scenes) is dealt out by the table srk_mm_tiles13: nine waves a
+        // 2 x 4 block that shares its operands (schur_mm_steps_blk), three waves their own compile-time tile lists
+        // (schur_mm_steps_row); a smaller grid row-major, tile u = wave + 12 s, every tile with its own operands.
+        const bool runs = nt == 13, blk = runs && wvu < 9;
+        unsigned onmask = 0; // slots whose sum is flushed
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
             int ti, tj;
@@ -2249,10 +1908,8 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             }
             ta[s] = __builtin_amdgcn_readfirstlane(16 * ti);
             tb[s] = __builtin_amdgcn_readfirstlane(16 * tj);
-            ns += on ? 1 : 0;
             onmask |= on ? 1u << s : 0u;
         }
-        ns = __builtin_amdgcn_readfirstlane(ns);
         onmask = __builtin_amdgcn_readfirstlane(onmask);
         srk_double4 acc[SRK_MM_SLOTS];
 #pragma unroll
@@ -2262,120 +1919,48 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
 #ifdef SRK_MM_STAMPS
         tacc = wall_clock64();
 #endif
-        // operand pattern of each half step, from the tile rows themselves (an idle slot multiplies tile (0, 0): any
-        // pattern its row happens to match is fine, its sum is never flushed)
-        auto pattern = [&](int s0) {
-            const int r0 = ta[s0], r1 = ta[s0 + 1], r2 = ta[s0 + 2], r3 = ta[s0 + 3];
-            if (!runs || blk) return 0;
-            if (r0 == r1 && r1 == r2 && r2 == r3) return 4;
-            if (r0 == r1 && r1 == r2) return 31;
-            if (r0 == r1 && r2 == r3) return 22;
-            if (r1 == r2 && r2 == r3) return 13;
-            return 0;
-        };
-        const int pat = __builtin_amdgcn_readfirstlane(100 * pattern(0) + pattern(4));
-        // the three waves that are not 2 x 4 blocks (one each on SIMDs 1 .. 3) read more operands per MFMA and wait before every
-        // one of them: alone at the end of a double round they would crawl -- they run ahead of the block waves instead
-        // (Schur phase 402.5 -> 397.5 us, six interleaved runs; priority 1, 2 or 3, helpers at 2 or 3: the same)
+        // the three waves that are not 2 x 4 blocks (one each on SIMDs 1 .. 3) read more operands per MFMA: alone at the end of
+        // a double round they would crawl -- they run ahead of the block waves instead (Schur phase 402.5 -> 397.5 us, six
+        // interleaved runs; priority 1, 2 or 3, helpers at 2 or 3: the same)
         if (runs && !blk) __builtin_amdgcn_s_setprio(1);
-        auto rounds = [&](auto p0, auto p1) {
-            if (!ragged) { // uniform runs: double rounds of Z^T Z (see the helpers), round u in buffer u % 6
-                for (int r = 0; r < R; r += 2) {
-                    const double* bw = sBuf + (r % 6) * WB;
-#if defined(SRK_SCH_NOACC) || defined(SRK_MM_NO_ROWWAVES) // (ablations, wrong results; NO_ROWWAVES: the three non-block waves multiply nothing)
-                    if (d.N < 0)
-#endif
-                    {
-                        schur_mm_steps<SRK_MM_SLOTS, decltype(p0)::value, decltype(p1)::value>(acc, bw, bw, ta, tb, lbase);
-                        if (r + 1 < R)
-                            schur_mm_steps<SRK_MM_SLOTS, decltype(p0)::value, decltype(p1)::value>(acc, bw + WB, bw + WB, ta, tb, lbase);
-                    }
-                    MM_ACC(0, 6, tacc);
-                    lds_barrier();
-                    MM_ACC(0, 7, tacc);
-                }
-                return;
-            }
-            int wi = 0; // W buffer of round r
-            for (int r = 0; r < R; ++r) {
-                const double* bw = sBuf + wi * WB;
-                const double* by = sBuf + (3 + (r & 1)) * WB;
-                wi = wi == 2 ? 0 : wi + 1;
-#ifdef SRK_SCH_NOACC
-                if (d.N < 0)
-#endif
-                schur_mm_steps<SRK_MM_SLOTS, decltype(p0)::value, decltype(p1)::value>(acc, bw, by, ta, tb, lbase); // idle slots multiply tile (0, 0)
-                MM_ACC(0, 6, tacc);
-#ifndef SRK_MM_NO_ROUND_BARRIER
-                lds_barrier();
-#endif
-                MM_ACC(0, 7, tacc);
-            }
-        };
-        auto rounds_row = [&](auto wc) { // waves 9 .. 11 of the full-size grid, uniform runs (schur_mm_steps_row)
+        auto double_rounds = [&](auto steps) { // steps(bw): the three K steps of the round staged at bw
             for (int r = 0; r < R; r += 2) {
                 const double* bw = sBuf + (r % 6) * WB;
-#if defined(SRK_SCH_NOACC) || defined(SRK_MM_NO_ROWWAVES)
+#ifdef SRK_SCH_NOACC // (ablation, wrong results)
                 if (d.N < 0)
 #endif
                 {
-                    schur_mm_steps_row<decltype(wc)::value>(acc, bw, lbase);
-                    if (r + 1 < R) schur_mm_steps_row<decltype(wc)::value>(acc, bw + WB, lbase);
+                    steps(bw);
+                    if (r + 1 < R) steps(bw + WB);
                 }
                 MM_ACC(0, 6, tacc);
                 lds_barrier();
                 MM_ACC(0, 7, tacc);
             }
         };
-        if (runs && !blk) {
-            if (wvu == 9) rounds_row(std::integral_constant<int, 0>{});
-            else if (wvu == 10) rounds_row(std::integral_constant<int, 1>{});
-            else rounds_row(std::integral_constant<int, 2>{});
-        } else if (blk) {
+        if (blk) {
             // a block that reaches over the diagonal (rows r, r + 1, columns r - 2 .. r + 1): its tile 3 = (r, r + 1) is never
-            // flushed -- not multiplied either (7 MFMAs a K step: with the table's tile counts the SIMDs hold 23, 23, 22, 23
-            // MFMAs a K step instead of 24 each)
+            // flushed -- not multiplied either (with the table's tile counts the SIMDs hold 23, 23, 22, 23 MFMAs a K step)
             const bool skip3 = __builtin_amdgcn_readfirstlane((int)(tb[3] > ta[3])) != 0;
-            for (int r = 0; r < R; r += 2) { // uniform runs: double rounds (see the helpers), round u in buffer u % 6
-                const double* bw = sBuf + (r % 6) * WB; // Z^T Z: both operands read the one staged array
-#ifdef SRK_SCH_NOACC
-                if (d.N < 0)
+            double_rounds([&](const double* bw) { schur_mm_steps_blk(acc, bw, bw, ta, tb, lbase, skip3); });
+        } else if (runs) {
+#ifdef SRK_MM_NO_ROWWAVES // ablation (wrong results): the three non-block waves multiply nothing
+            double_rounds([&](const double*) {});
+#else
+            if (wvu == 9) double_rounds([&](const double* bw) { schur_mm_steps_row<0>(acc, bw, lbase); });
+            else if (wvu == 10) double_rounds([&](const double* bw) { schur_mm_steps_row<1>(acc, bw, lbase); });
+            else double_rounds([&](const double* bw) { schur_mm_steps_row<2>(acc, bw, lbase); });
 #endif
-                {
-                    schur_mm_steps_blk(acc, bw, bw, ta, tb, lbase, skip3);
-                    if (r + 1 < R) schur_mm_steps_blk(acc, bw + WB, bw + WB, ta, tb, lbase, skip3);
-                }
-                MM_ACC(0, 6, tacc);
-#ifndef SRK_MM_NO_ROUND_BARRIER
-                lds_barrier();
-#endif
-                MM_ACC(0, 7, tacc);
-            }
         } else {
-            using std::integral_constant;
-#define SRK_MM_CASE(A, B) case 100 * A + B: rounds(integral_constant<int, A>{}, integral_constant<int, B>{}); break
-            switch (pat) { // the patterns of the nt = 13 runs; anything else takes the general form
-            SRK_MM_CASE(4, 4);
-            SRK_MM_CASE(4, 0);
-            SRK_MM_CASE(4, 13);
-            SRK_MM_CASE(4, 22);
-            SRK_MM_CASE(4, 31);
-            SRK_MM_CASE(22, 4);
-            SRK_MM_CASE(22, 31);
-            SRK_MM_CASE(0, 22);
-            SRK_MM_CASE(31, 4);
-            default: rounds(integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
-            }
-#undef SRK_MM_CASE
+            double_rounds([&](const double* bw) { schur_mm_steps(acc, bw, bw, ta, tb, lbase); }); // idle slots multiply tile (0, 0)
         }
         MM_STAMP(3);
         // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg.
-        // (Round 3) Straight from the accumulator registers: every lane adds its entries on and below the diagonal of the
-        // sum (row >= column: S is lower-triangle authoritative; the parts of the diagonal 10 x 10 blocks above it, which the
-        // LDS flush also wrote, are never read).  The LDS flush -- three or four passes of tile rows through the arena, two
+        // Straight from the accumulator registers: every lane adds its entries on and below the diagonal of the sum (row >=
+        // column: S is lower-triangle authoritative).  The LDS flush this replaced -- passes of tile rows through the arena, two
         // barriers each, then one wave per row of S -- took 12.8 us of a workgroup's 98; its atomics themselves cost nothing
         // since the staggered start (SRK_SCH_NOFLUSH: 429.5 against 430 us), so what it spent was the shuffling.  A wave's
-        // atomic instruction covers 16 consecutive columns of four rows of S.  Schur phase 432-435 -> 425 us.
+        // atomic instruction covers 16 consecutive columns of four rows of S.
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
             if (!((onmask >> s) & 1u)) continue;
@@ -2395,7 +1980,7 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         }
     }
     lds_barrier(); // the helpers' sRhs adds are complete
-    // rhs += sum F^T E^-1 g (the helpers' sRhs adds precede a barrier every wave passes)
+    // rhs += sum F^T E^-1 g
     if (tid < nf10 && sVar[tid] >= 0) atomicAdd(&rhs[sVar[tid]], sRhs[tid]);
     MM_STAMP(4);
 #ifdef SRK_MM_STAMPS
@@ -2717,7 +2302,7 @@ __global__ __launch_bounds__(256) void k_backsub_obs(SrkDims d, const int32_t* _
         double xv[10];
 #pragma unroll
         for (int fv = 0; fv < 10; ++fv) xv[fv] = x[fv];
-        if constexpr (WStore<WT>::factored) {
+        {
             // W x = Ap (Af . x) + Bp (Bf . x): 21 loads and 22 multiply-adds instead of 30 and 30
             const WT* wp = W + o;
             const double gq = wp[(int64_t)SRK_WF_G * d.Os];
@@ -2731,11 +2316,6 @@ __global__ __launch_bounds__(256) void k_backsub_obs(SrkDims d, const int32_t* _
 #pragma unroll
             for (int pv = 0; pv < 3; ++pv)
                 t[pv] = wp[(int64_t)(SRK_WF_AP + pv) * d.Os] * sa + wp[(int64_t)(SRK_WF_BP + pv) * d.Os] * sb;
-        } else {
-#pragma unroll
-            for (int pv = 0; pv < 3; ++pv)
-#pragma unroll
-                for (int fv = 0; fv < 10; ++fv) t[pv] += W[(int64_t)(10 * pv + fv) * d.Os + o] * xv[fv];
         }
     }
 #pragma unroll
