@@ -1961,21 +1961,35 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         // barriers each, then one wave per row of S -- took 12.8 us of a workgroup's 98; its atomics themselves cost nothing
         // since the staggered start (SRK_SCH_NOFLUSH: 429.5 against 430 us), so what it spent was the shuffling.  A wave's
         // atomic instruction covers 16 consecutive columns of four rows of S.
+        // (the four rows of a lane and their places in S are formed once per TILE ROW -- consecutive slots of a wave mostly share
+        // it -- not once per entry: every vector-ALU instruction here is paid in MFMA time by the next workgroup's neighbours)
+        int prev_ta = -1, rr4[4];
+        int64_t rowoff[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { rr4[reg] = -1; rowoff[reg] = 0; }
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
             if (!((onmask >> s) & 1u)) continue;
+            if (ta[s] != prev_ta) { // wave-uniform
+                prev_ta = ta[s];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int Rr = ta[s] + lk + 4 * reg;
+                    const int rowv = Rr < nf10 ? sVar[Rr] : -1;
+                    rr4[reg] = rowv >= 0 ? Rr : -1; // -1: no such row, or a gauge-fixed variable
+                    rowoff[reg] = (int64_t)rowv * d.ld;
+                }
+            }
             const int Cc = tb[s] + lr;
             const int colv = Cc < nf10 ? sVar[Cc] : -1;
+            if (colv < 0) continue;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int Rr = ta[s] + lk + 4 * reg;
-                if (colv < 0 || Rr >= nf10 || Cc > Rr) continue;
-                const int rowv = sVar[Rr];
-                if (rowv < 0) continue;
+                if (Cc > rr4[reg]) continue; // above the diagonal, or no row
 #ifdef SRK_SCH_NOFLUSH
                 if (d.N >= 0) continue;
 #endif
-                atomicAdd(&S[(int64_t)rowv * d.ld + colv], -acc[s][reg]);
+                atomicAdd(&S[rowoff[reg] + colv], -acc[s][reg]);
             }
         }
     }
