@@ -24,8 +24,11 @@ def run(rank, world, port, out_dir, spec_kwargs, iters, schedule="dp"):
     try:
         spec_kwargs = dict(spec_kwargs)
         shuffle = spec_kwargs.pop("_shuffle", None)
+        drop = spec_kwargs.pop("_drop", None)
         spec = sa.SceneSpec(**spec_kwargs)
         full = sa.generate_scene(spec)
+        if drop is not None:  # ragged tracks: hardly two landmarks see the same frames
+            full = sa.drop_observations(full, drop, seed=11)
         if shuffle is not None:  # an unordered image set: the frame numbers say nothing about covisibility
             full = sa.renumber_frames(full, np.random.RandomState(shuffle).permutation(full.M))
         ok, nrm = sa.normalize_scene_inplace(full)

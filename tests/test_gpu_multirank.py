@@ -44,16 +44,21 @@ C3 = dict(n_frames=1000, grid_nx=400, grid_ny=250, vis_window=20)
     (4, C3, 8, "dp"),
     # frame numbers shuffled: every rank is given the numbering found on the whole scene (srk_ba_set_frame_order)
     (2, dict(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2, _shuffle=3), 2, "dp"),
+    # ragged tracks (20 % of the observations dropped): the shards' runs are unions of frame lists (masked Schur / derivative kernels)
+    (3, dict(n_frames=400, grid_nx=80, grid_ny=50, vis_window=16, noise_uv_pix=0.2, _drop=0.2), 2, "dp"),
 ], ids=["w2_30cam", "w2_30cam_allreduce", "w3_400cam", "w3_400cam_allreduce", "w2_C3_1kcam_100kpt", "w4_C3_1kcam_100kpt",
-        "w2_400cam_frames_shuffled"])
+        "w2_400cam_frames_shuffled", "w3_400cam_ragged"])
 def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs, min_chunks, schedule):
     import torch.multiprocessing as mp
     import _dist_gpu_worker
     iters = 3  # far from convergence: no accept / reject decision is a near tie that summation order could flip
     kw = dict(spec_kwargs)
     shuffle = kw.pop("_shuffle", None)
+    drop = kw.pop("_drop", None)
     spec = sa.SceneSpec(**kw)
     ref = sa.generate_scene(spec)
+    if drop is not None:
+        ref = sa.drop_observations(ref, drop, seed=11)
     if shuffle is not None:
         ref = sa.renumber_frames(ref, np.random.RandomState(shuffle).permutation(ref.M))
     ba = sa.BundleAdjustmentKanatani(0)
