@@ -864,6 +864,11 @@ static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr
     std::vector<int32_t> comp;
     for (int32_t start = 0; start < M; ++start) {
         if (done[(size_t)start]) continue;
+        if (deg[(size_t)start] == 0) { // a frame nobody shares a landmark with: a component of its own
+            done[(size_t)start] = 1;
+            order.push_back(start);
+            continue;
+        }
         int32_t root = start, depth = -1, d2 = 0;
         for (int it = 0; it < 4; ++it) { // George-Liu: walk to a frame of (nearly) greatest eccentricity
             const int32_t far = bfs(root, comp, d2);
