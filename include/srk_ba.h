@@ -250,7 +250,9 @@ double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates o
 /* Solver launch structure (harness knob; the reference has one dense solve, bundle-adj-kanatani.cpp:1911): 1 (default) =
  * each 256-column outer step of the blocked Cholesky is ONE launch whose workgroups hand factored tiles to one another
  * (bounded spins; a timed-out hand-off makes the LM loop repeat that attempt with the unfused sequence and stay there),
- * 0 = one launch per 64-column panel and per rank-64 update.  Both give bit-identical results.  Takes effect at once.
+ * 0 = one launch per 64-column panel and per rank-64 update.  Each is bit-reproducible from run to run; they agree with each
+ * other to rounding (since round 4 the fused step eliminates the diagonal block's own rows in the factorisation's unscaled
+ * form).  Takes effect at once.
  * srk_ba_solver_sync_timeouts: how many solves had to be repeated (0 in every run so far).  A timeout is a scheduling event
  * (another process on the GPU, a debugger), so the unfused sequence is kept only for the rest of that call: the next upload /
  * optimise call uses the fused step again -- until the handle has seen three timeouts since the last
@@ -258,6 +260,13 @@ double srk_ba_solve_mfma_flops(srk_ba*); /* flops of the MFMA trailing updates o
 int srk_ba_set_solver_fusion(srk_ba*, int on);
 int64_t srk_ba_solver_sync_timeouts(srk_ba*);
 int srk_ba_solver_fusion(srk_ba*);
+
+/* The accepted outer iterations of the last srk_ba_optimize / srk_ba_compute_inplace call (the reference logs them with
+ * VLOG, bundle-adj-kanatani.cpp:756-891): for iteration k the attempts it needed (solve + apply + error each), the host
+ * time in ms since the call began at which it was accepted, the error it reached and the damping factor that was
+ * accepted.  Returns the number of iterations (arrays, each may be NULL, receive at most cap entries). */
+int64_t srk_ba_iteration_log(srk_ba*, int64_t cap, int32_t* attempts, double* ms_since_start, double* err,
+                             double* hessian_factor);
 
 /* Speculative attempts (default on; takes effect at the next upload): with the instrumentation off
  * (srk_ba_set_profile 0, the default) the LM loop runs the next damping factor on a second stream beside the current

@@ -11,14 +11,18 @@
  * Build: gcc -O2 -std=c99 -fPIC -shared (no -ffast-math, no -march: plain IEEE mul/add).
  */
 #define _POSIX_C_SOURCE 199309L
-#include "ba_oracle.h"
 #include <math.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef ORC_F32 /* the reference's Scalar = float: see "Scalar type" below.  Behind the system headers, in front of everything of this file */
+#define double float
+#endif
+#include "ba_oracle.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -45,15 +49,31 @@ int orc_get_threads(void) { return orc_threads; }
  * the same Schur arithmetic on skyline storage and a skyline Cholesky (orc_two_phase_skyline).  Used by bench.py's
  * cpu_baseline leg for a complete iteration of the 1000-camera scene (its 9993^2 QR would take hours) and checked
  * against the QR on the small configurations by tests/test_oracle_skyline.py. */
+/* Scalar type.  The reference is templated on `Scalar` (rt-config.h:41-48): double by default, float when CMake is given
+ * suriko_scalar_type_string=f32 (suriko-engine/CMakeLists.txt:14-15,76-82).  `make libba_oracle_f32.so` compiles THIS file a
+ * second time with -DORC_F32 (`double` is then a macro for float behind the system headers): every variable, every array of the interface and every intermediate then is a
+ * float, which is what the reference's f32 build computes in (the libm calls go through double and are rounded once, within
+ * an ulp of sqrtf and friends).  What changes with the type besides the arithmetic: Eigen's
+ * NumTraits<Scalar>::dummy_precision(), the invertibility threshold of computeInverseAndDetWithCheck (:1876), is 1e-12 for
+ * double and 1e-5 for float. */
+#ifdef ORC_F32
+#define ORC_DUMMY_PRECISION 1e-5f
+#else
+#define ORC_DUMMY_PRECISION 1e-12
+#endif
+int orc_scalar_bytes(void) { return (int)sizeof(double); } /* 8, or 4 in the f32 build */
 static int orc_solver = 0;
 void orc_set_solver(int mode) { orc_solver = mode == 1 ? 1 : 0; }
 int orc_get_solver(void) { return orc_solver; }
 
+/* (the f32 build below redefines `double`; a float cannot hold a monotonic clock, so seconds are taken relative to the first call) */
 static double now_sec(void)
 {
+    static long long t0_sec = -1;
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    if (t0_sec < 0) t0_sec = (long long)ts.tv_sec;
+    return (double)((long long)ts.tv_sec - t0_sec) + (double)(1e-9f * (float)ts.tv_nsec);
 }
 
 /* ---------------------------------------------------------------- small helpers */
@@ -259,7 +279,7 @@ int orc_inverse3x3_with_check(const double A[9], double Ainv[9], double* det_out
     double c20 = A_(1, 0) * A_(2, 1) - A_(1, 1) * A_(2, 0); /* cofactor(0,2) */
     double det = A_(0, 0) * c00 + A_(0, 1) * c10 + A_(0, 2) * c20;
     if (det_out) *det_out = det;
-    if (!(fabs(det) > 1e-12)) return 0;
+    if (!(fabs(det) > ORC_DUMMY_PRECISION)) return 0;
     double id = 1 / det;
     Ainv[0] = c00 * id;
     Ainv[1] = (A_(0, 2) * A_(2, 1) - A_(0, 1) * A_(2, 2)) * id;

@@ -326,6 +326,20 @@ class BundleAdjustmentKanatani:
         self._lib.srk_ba_solver_sync_timeouts.restype = C.c_int64
         return int(self._lib.srk_ba_solver_sync_timeouts(C.c_void_p(self._h)))
 
+    def iteration_log(self):
+        """accepted iterations of the last optimise / ComputeInplace call: dict of arrays attempts, ms (host time since the
+        call began), err, hessian_factor (srk_ba_iteration_log)"""
+        fn = self._lib.srk_ba_iteration_log
+        fn.restype = C.c_int64
+        n = int(fn(C.c_void_p(self._h), C.c_int64(0), None, None, None, None))
+        att = np.zeros(max(n, 1), dtype=np.int32)
+        ms = np.zeros(max(n, 1))
+        err = np.zeros(max(n, 1))
+        fac = np.zeros(max(n, 1))
+        fn(C.c_void_p(self._h), C.c_int64(n), att.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p),
+           err.ctypes.data_as(C.c_void_p), fac.ctypes.data_as(C.c_void_p))
+        return {"attempts": att[:n], "ms": ms[:n], "err": err[:n], "hessian_factor": fac[:n]}
+
     def set_jacobian_mode(self, mode=-1):
         """-1 automatic, 0 = per-observation kernels only, 1 = run-based (uniform runs) whenever possible, 2 = run-based over
         frame unions (ragged tracks) whenever possible (next upload)"""

@@ -155,6 +155,8 @@ struct srk_ba {
     bool chol_fused_wanted = true;
     int fusion_rearms_left = 3; // SRK_FUSION_RETRIES
     int64_t sync_timeouts = 0; // solves repeated with the unfused kernels after a hand-off timed out
+    struct IterLog { int32_t attempts; double ms, err, factor; };
+    std::vector<IterLog> iter_log; // the accepted iterations of the last optimise call (srk_ba_iteration_log)
     int last_slot = 0;     // attempt slot of the last judged attempt (what SRK_BUF_RCS / RHS / CORRECTIONS download)
     double last_hessian_factor = 0;
     bool lean_resets = false; // srk_ba_optimize: no per-attempt memsets (see phase_solve)
@@ -1912,6 +1914,7 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
     hipStream_t s = h->stream;
     const SrkDims& d = h->d;
     auto t_begin = std::chrono::steady_clock::now();
+    h->iter_log.clear();
     rep->world_scale = h->nrm.world_scale;
     rearm_fusion(h);
     {
@@ -2273,6 +2276,9 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             h->cur = newcur;
         }
         rep->iterations += 1;
+        if (h->iter_log.size() < (size_t)1 << 20)
+            h->iter_log.push_back({ (int32_t)prev_attempts, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                                    err_new, hessian_factor });
         double change = err_new - err_value;
         rep->err_final = err_new;
         if (allowed_err_change && std::fabs(change) < *allowed_err_change) { // :880-884
@@ -2894,6 +2900,18 @@ int srk_ba_set_solver_fusion(srk_ba* h, int on)
     return SRK_OK;
 }
 int64_t srk_ba_solver_sync_timeouts(srk_ba* h) { return h ? h->sync_timeouts : -1; }
+int64_t srk_ba_iteration_log(srk_ba* h, int64_t cap, int32_t* attempts, double* ms_since_start, double* err, double* hessian_factor)
+{
+    if (!h) return -1;
+    const int64_t n = (int64_t)h->iter_log.size();
+    for (int64_t k = 0; k < n && k < cap; ++k) {
+        if (attempts) attempts[k] = h->iter_log[k].attempts;
+        if (ms_since_start) ms_since_start[k] = h->iter_log[k].ms;
+        if (err) err[k] = h->iter_log[k].err;
+        if (hessian_factor) hessian_factor[k] = h->iter_log[k].factor;
+    }
+    return n;
+}
 int srk_ba_solver_fusion(srk_ba* h) { return h ? (h->chol_fused ? 1 : 0) : -1; }
 
 int srk_ba_set_speculation(srk_ba* h, int on)

@@ -110,8 +110,11 @@ __device__ __forceinline__ double fast_rcp1(double d)
 #ifndef SRK_POTRF_RCP
 #define SRK_POTRF_RCP fast_rcp1
 #endif
+// PUB (the diagonal-block workgroup of k_step256, whose other waves carry passenger rows): the threads also publish every
+// group's 4 x 4 factor (u_jk below the diagonal, 1 / d_k) in sF [2][64] before the group's SECOND barrier, and 1 / sqrt(d) in sRsq.
+template <bool PUB>
 __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][64][4]: panel P, finals Y (two buffers)*/,
-                                        double* sDiag /*[64]*/, double* sInv /*[64]*/)
+                                        double* sDiag /*[64]*/, double* sInv /*[64]*/, double* sF, double* sRsq)
 {
     const int t = threadIdx.x, i = t >> 2, q = t & 3;
     double (*sP)[4] = reinterpret_cast<double (*)[4]>(sPY);
@@ -166,9 +169,20 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][
             const double y01 = (q & 1) ? y1 : y0, y23 = (q & 1) ? y3 : y2;
             a[g] = (q & 2) ? y23 : y01; // final (unscaled) entry of column 4g + q
         }
+        double fv = 0; // PUB: lane l < 10 of every wave publishes value l of the factor (no branch inside the round, no two
+        // lanes on one word; the waves store the same numbers) -- behind the group's first barrier, where the chain waits
+        // for LDS anyway (the last reciprocal is not needed before it)
+        if (PUB) {
+            const int l = t & 63;
+            fv = u10;
+            fv = l == 1 ? u20 : fv, fv = l == 2 ? u30 : fv, fv = l == 3 ? u21 : fv, fv = l == 4 ? u31 : fv, fv = l == 5 ? u32 : fv;
+            fv = l == 6 ? r0 : fv, fv = l == 7 ? r1 : fv, fv = l == 8 ? r2 : fv, fv = l == 9 ? r3 : fv;
+            if (g == 15) sF[64 * (g & 1) + l] = fv;
+        }
         if (g == 15) break;
         sY[i][q] = a[g];
         lds_barrier();
+        if (PUB) sF[64 * (g & 1) + (t & 63)] = fv;
         // the next group's slot: update, publish, barrier -- the remaining slots follow behind that barrier (above)
         {
             const double2* yp = reinterpret_cast<const double2*>(&sY[4 * (g + 1) + q][0]);
@@ -184,7 +198,10 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][
     for (int m = 0; m < 16; ++m)
         if (4 * m + q == i) sDiag[i] = a[m];
     lds_barrier();
-    if (t < NB) sInv[t] = fast_rsqrt(sDiag[t]); // 1 / L_tt
+    if (t < NB) {
+        sInv[t] = fast_rsqrt(sDiag[t]); // 1 / L_tt
+        if (PUB) sRsq[t] = sInv[t];
+    }
     lds_barrier();
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(256) void k_panel(const CholBatch B, const CholStep
 #pragma unroll
     for (int m = 0; m < 16; ++m) a[m] = row[4 * m + q];
     // (issued before the tile is factored: the loads' latency, ~1.5 us after the factorisation, hides under it)
-    bool bad = potrf64(sD, sCol, sDiag, sInv);
+    bool bad = potrf64<false>(sD, sCol, sDiag, sInv, nullptr, nullptr);
     STAMP(2);
     if (bad && inv_wg && threadIdx.x == 0) atomicOr(info, 1);
     // The factored tile is never stored back into A: the other workgroups of this launch read the unfactored tile from
@@ -546,34 +563,66 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
 
 // ---------------------------------------------------------------- fused outer step: the four inner panels in ONE launch
 // The k_panel / k_upd64 sequence costs an outer step 4 x 20 + 3 x 8.5 us although its critical path -- factor tile d,
-// sweep the 64 rows of tile d + 1, update tile (d + 1, d + 1), factor it -- is ~17 us a tile: every panel launch loads,
+// sweep the 64 rows of tile d + 1, update tile (d + 1, d + 1), factor it -- is far shorter: every panel launch loads,
 // factors the diagonal tile redundantly in every workgroup, sweeps ALL rows and stores before the update launch may
-// start.  k_step256 runs the whole outer step as one launch of workgroups with roles, ordered by blockIdx.x so that a
-// workgroup only ever waits for workgroups of LOWER index of its own item (blockIdx.z):
-//   x = 0..3  diagonal workgroup t: the 64 rows of tile row t of the 256 x 256 diagonal block.  Sub-steps d < t: it sweeps
-//             its rows against L_dd, PUBLISHES X_td (= L's tile (t, d), in place in A), applies the rank-64 update to its
-//             tiles (t, d + 1 .. t); sub-step t: factors its diagonal tile (the last update went straight into LDS),
-//             publishes L_tt, forms y_t = L_tt^-1 w_t and publishes it.
-//   x = 4     inverse workgroup: L_dd^-1 of the four tiles as they appear (for the backward substitution).
-//   x >= 5    row workgroups: 64 rows each of the rows below the diagonal block (skyline rows, then the live border rows);
-//             per sub-step: wait for L_dd, sweep, wait for y_d and X_td (t > d), update w and the tiles (., d + 1 .. 3).
+// start.  k_step256 runs the whole outer step as one launch of 512-thread workgroups with roles (blockIdx.x), ordered so
+// that a workgroup only ever waits for the workgroup of LOWER index of its own item (blockIdx.z):
+//   x = 0   DIAGONAL-BLOCK workgroup (round 4): ONE workgroup owns the whole 256 x 256 diagonal block for all four
+//           sub-steps, so the factorisation chain crosses no global-memory hand-off (rounds 2 / 3: tile row t lived in
+//           workgroup t and every sub-step paid flag 0.9 + tile load 2.2 + publish X 1.4 + publish L 1.3 us on the chain).
+//           Sub-step d:  P(d)  waves 0-3 factor tile (d, d) (potrf64, in LDS + registers) while waves 4-7 carry the rows of
+//                              the tiles (t, d), t > d, below it as PASSENGER rows: they eliminate their rows against each
+//                              group's 4 x 4 factor (published through LDS) one group behind the chain, so X_td = A_td
+//                              L_dd^-T is complete when L_dd is -- the 4 us sweep of the next tile row is off the chain;
+//                        pub   waves 0-3 issue the write-through stores of L_dd and the X_td and set F(d) when drained, beside
+//                        U(d)  the rank-64 updates C -= X_td X_(d+1)d^T of the NEXT PANEL's tiles (t, d + 1), as fp64 MFMA
+//                              sub-tiles dealt to the eight waves by a static table (srk_step_tables.inc); the results are
+//                              held in registers until every wave is done with the X tiles in LDS, then go there.  (One CU's
+//                              fp64 pipe takes 0.17 us a sub-tile: with ALL tiles of the block here the updates cost what
+//                              the hand-offs had -- the tiles behind the next panel are the helper workgroups'.)
+//   x = 1   inverse workgroup: L_dd^-1 of the four tiles as they appear (for the backward substitution).
+//   x = 2   forward-substitution workgroup: y_d = L_dd^-1 w_d as the tiles appear (flag Y(d)), w_t -= X_td y_d for the block's
+//           rows below.  (Inside the diagonal-block workgroup the 64 dependent steps took 4 - 8 us of a wave whose SIMD was
+//           streaming MFMAs.)
+//   x = 3..5  helper workgroups: the tiles (2, 2), (3, 2), (3, 3) of the diagonal block -- the ones behind the next panel -- take
+//           their rank-64 updates of the sub-steps d <= c - 2 here, from the published X tiles, and go back with flag G: the ONLY
+//           wait of the diagonal-block workgroup, for indices 3..5 of its own item, with a whole factorisation of slack.
+//   x >= 6  row workgroups: 64 rows each of the rows below the diagonal block (skyline rows, then the live border rows);
+//           per sub-step: wait for F(d), sweep against L_dd, update w with y_(d-1), update the tiles (., d + 1 .. 3) with the
+//           published X_td.  One-way consumers: nothing waits for them inside the launch.
 // Hand-offs follow the guide's recipe (cdna_hip_programming.md, Guideline 16 R1): payload stored write-through (sc1
-// stores), every storing wave drains, workgroup barrier, ONE lane stores the flag (sc1); the consumer polls that word
-// relaxed from one lane, ONE agent-scope acquire, barrier, then plain loads.  A flag word holds the EPOCH of the launch
-// that set it (the host counts launches per stream), so nothing is ever reset.  Every spin is bounded: a timeout sets
-// bit 8 of *info and the workgroup carries on (wrong numbers, flagged; the host repeats the solve with the unfused
-// kernels).  Deadlock: dispatch is in order of the linear workgroup index per XCD and a workgroup waits only for lower
-// indices, so the lowest unfinished index is always resident or first in line; the host keeps a launch within 256
-// workgroups, so that two of them (the two attempt slots) cannot fill an XCD with waiting workgroups.
-// Arithmetic: that of k_panel / k_upd64 (same potrf64, same sweep, same MFMA update order per tile).
-#define ST_F(d) (d)                                 // flag words of an item: L_dd published
+// stores), every storing wave drains and counts itself in (LDS counter), the LAST one stores the flag (sc1); the consumer
+// polls that word relaxed from one lane, ONE agent-scope acquire, barrier, then plain loads.  A flag word holds the EPOCH of
+// the launch that set it (the host counts launches per stream), so nothing is ever reset.  Every spin is bounded: a timeout
+// sets bit 8 of *info and the workgroup carries on (wrong numbers, flagged; the host repeats the solve with the unfused
+// kernels).  Deadlock: dispatch is in order of the linear workgroup index per XCD; every workgroup but index 0 waits only
+// for index 0 of its item, index 0 only for indices 3..5, which wait only for index 0: whenever the lowest unfinished
+// workgroup of an item is resident, the ones it can wait for are resident or first in line; the host keeps a launch within
+// 256 workgroups.
+// Arithmetic: potrf64 as in k_panel; the block's own rows are eliminated in the unscaled (L D L^T) form of potrf64 instead of
+// k_panel's substitution against the stored factor, so the fused and the unfused sequences agree to rounding, not bit for bit.
+#include "srk_step_tables.inc"
+#define ST_F(d) (d)                                 // flag words of an item: L_dd and the X_td published
 #define ST_Y(d) (4 + (d))                           // y_d published
-#define ST_G(t, d) (8 + (t) * ((t) - 1) / 2 + (d))  // X_td published, 1 <= t <= 3, d < t
+#define ST_G(k) (8 + (k))                           // helper k is done with its tile: (2, 2), (3, 2), (3, 3)
 #define ST_WORDS 16
 #define ST_SPIN_MAX (1 << 17)
 #ifndef ST_POLL_SLEEP
 #define ST_POLL_SLEEP 2
 #endif
+#define STP_THREADS 512
+#define STP_TILE (NB * LDSP)                        // a 64 x 64 tile in LDS, row stride NB + 2
+// LDS map of the kernel (doubles)
+#define STP_COL (4 * STP_TILE)                      // potrf64 exchange: panel + two buffers of finals [12 NB]
+#define STP_F (STP_COL + 12 * NB)                   // 4 x 4 factors of two groups [2][64] (ten words used)
+#define STP_DIAG (STP_F + 2 * NB)
+#define STP_INV (STP_DIAG + NB)
+#define STP_RSQ (STP_INV + NB)
+#define STP_Y (STP_RSQ + NB)
+#define STP_W (STP_Y + NB)                          // (inverse workgroup) w_d
+#define STP_CNT (STP_W + NB)                        // publication counters (unsigned [8]) + fault word
+#define STP_LDS_DOUBLES (STP_CNT + 8)
+static_assert(STP_LDS_DOUBLES * sizeof(double) <= 160 * 1024, "one workgroup per CU");
 typedef unsigned int __attribute__((address_space(1))) gu32_t;
 __device__ __forceinline__ void st_store(double* p, double v) // write-through store (global_store_dwordx2 sc1)
 {
@@ -590,12 +639,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) // l: wave-unifo
     lo = __builtin_amdgcn_readlane(lo, l);
     hi = __builtin_amdgcn_readlane(hi, l);
     return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void st_publish(unsigned* f, unsigned epoch)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains its write-through stores
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wait until every flag word of `mask` holds `epoch`; one lane polls, one acquire, then the workgroup's barrier
 __device__ __forceinline__ void st_wait(unsigned* fl, unsigned mask, unsigned epoch, int* info)
@@ -621,11 +664,33 @@ __device__ __forceinline__ void st_wait(unsigned* fl, unsigned mask, unsigned ep
     }
     __syncthreads();
 }
-// 64 x 64 tile at T (row stride ld) -> sD; lower: zeros above the diagonal
-template <bool LOWER> __device__ __forceinline__ void st_load_tile(double (*sD)[NB + 2], const double* __restrict__ T, int64_t ld)
+// the same for ONE wave (no barrier): lane 0 polls, the wave acquires
+__device__ __forceinline__ void st_wait_wave(unsigned* fl, unsigned mask, unsigned epoch, int* info)
+{
+    if ((threadIdx.x & 63) == 0) {
+        unsigned pending = mask;
+        int spins = 0;
+        while (pending) {
+            const int k = __ffs(pending) - 1;
+            if (__hip_atomic_load(fl + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+                pending &= pending - 1;
+                continue;
+            }
+            if (++spins > ST_SPIN_MAX || ((spins & 63) == 0 && (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8))) {
+                atomicOr(info, 8);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(ST_POLL_SLEEP);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// 64 x 64 tile at G (row stride ld) -> sD, by the first 256 threads; LOWER: zeros above the diagonal
+template <bool LOWER> __device__ __forceinline__ void st_load_tile(double (*sD)[LDSP], const double* __restrict__ G, int64_t ld)
 {
     const int i = threadIdx.x >> 2, cb = (threadIdx.x & 3) * 16;
-    const double2* src = reinterpret_cast<const double2*>(T + (int64_t)i * ld + cb);
+    const double2* src = reinterpret_cast<const double2*>(G + (int64_t)i * ld + cb);
     double2 v[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = src[t];
@@ -636,19 +701,361 @@ template <bool LOWER> __device__ __forceinline__ void st_load_tile(double (*sD)[
         sD[i][c + 1] = (!LOWER || c + 1 <= i) ? v[t].y : 0.0;
     }
 }
-// test hook (srk_dbg_step_fault): the next N launches' first diagonal workgroup of item 0 does not publish L_00 -- every
-// consumer of that item runs into its spin bound, bit 8 of *info is set and the host repeats the solve unfused
+// the same by all 512 threads (no masking): thread -> row tid >> 3, eight doubles from column 8 (tid & 7)
+__device__ __forceinline__ void st_load_tile512(double (*sD)[LDSP], const double* __restrict__ G, int64_t ld)
+{
+    const int i = threadIdx.x >> 3, cb = (threadIdx.x & 7) * 8;
+    const double2* src = reinterpret_cast<const double2*>(G + (int64_t)i * ld + cb);
+    double2 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = src[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        sD[i][cb + 2 * t] = v[t].x;
+        sD[i][cb + 2 * t + 1] = v[t].y;
+    }
+}
+// test hook (srk_dbg_step_fault): the next N launches' diagonal-block workgroup of item 0 stops after its first tile and
+// publishes nothing -- every consumer of that item runs into its spin bound, bit 8 of *info is set and the host repeats
+// the solve unfused
 __device__ int g_step_fault = 0;
 extern "C" void srk_dbg_step_fault(int launches) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_fault), &launches, sizeof(int)); }
 #ifdef SRK_STEP_STAMPS // development (tools/step_stamps.sh): wall-clock stamps of item 0's workgroups of one launch
 __device__ long long g_step_stamps[8][32];
-#define SST(k) do { if (blockIdx.z == 0 && K == 0 && threadIdx.x == 0 && blockIdx.x < 8) g_step_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
+#define SST(k) do { if (blockIdx.z == 0 && K == 0 && (threadIdx.x & 255) == 0 && blockIdx.x < 4) g_step_stamps[2 * blockIdx.x + (threadIdx.x >> 8)][k] = wall_clock64(); } while (0)
 extern "C" void srk_dbg_step_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_stamps), sizeof(long long) * 256); }
 #else
 #define SST(k)
 #endif
-__global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
-                                                     int64_t K, unsigned* __restrict__ flags, unsigned epoch, int* __restrict__ info)
+
+// ---- passenger rows of potrf64 (waves 4-7 of the diagonal-block workgroup)
+// One group of four columns on NP passenger rows per thread: eliminate the rows' entries of group g against the group's
+// 4 x 4 factor (u_jk, 1 / d_k as the chain published them), keep the finals, apply the rank-4 term to the slots behind.
+template <int NP> __device__ __forceinline__ void passenger_group(double (&a)[3][16], const int g, const double* sPY, const double* sF, const int q)
+{
+    const double2* F = reinterpret_cast<const double2*>(sF + 64 * (g & 1));
+    const double2* sY = reinterpret_cast<const double2*>(sPY + 4 * NB * (1 + (g & 1))) + 2 * q; // [row][2]: finals of this lane's column rows
+    const double2 f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4];
+    // the finals of the first eight slots behind the group are requested before the elimination (they do not depend on it): a
+    // fenced read-then-update loop left the wave four exposed LDS round trips a round, as long as the chain's own round
+    constexpr int H = 8;
+    double2 ya[H], yb[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k)
+        if (g + 1 + k < 16) ya[k] = sY[2 * 4 * (g + 1 + k)], yb[k] = sY[2 * 4 * (g + 1 + k) + 1];
+    const double u10 = f0.x, u20 = f0.y, u30 = f1.x, u21 = f1.y, u31 = f2.x, u32 = f2.y, r0 = f3.x, r1 = f3.y, r2 = f4.x, r3 = f4.y;
+    double z[NP > 0 ? NP : 1][4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const double p0 = quad_bcast<0>(a[p][g]), p1 = quad_bcast<1>(a[p][g]), p2 = quad_bcast<2>(a[p][g]), p3 = quad_bcast<3>(a[p][g]);
+        const double y0 = p0, z0 = y0 * r0;
+        const double y1 = fma(-z0, u10, p1), z1 = y1 * r1;
+        const double y2 = fma(-z1, u21, fma(-z0, u20, p2)), z2 = y2 * r2;
+        const double y3 = fma(-z2, u32, fma(-z1, u31, fma(-z0, u30, p3))), z3 = y3 * r3;
+        const double y01 = (q & 1) ? y1 : y0, y23 = (q & 1) ? y3 : y2;
+        a[p][g] = (q & 2) ? y23 : y01; // final (unscaled) entry of column 4g + q
+        z[p][0] = z0, z[p][1] = z1, z[p][2] = z2, z[p][3] = z3;
+    }
+    asm volatile("" ::: "memory");
+    double2 yc[H], yd[H]; // the slots behind those: in flight while the first eight are updated
+#pragma unroll
+    for (int k = 0; k < H; ++k)
+        if (g + 1 + H + k < 16) yc[k] = sY[2 * 4 * (g + 1 + H + k)], yd[k] = sY[2 * 4 * (g + 1 + H + k) + 1];
+#pragma unroll
+    for (int k = 0; k < H; ++k)
+        if (g + 1 + k < 16) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                a[p][g + 1 + k] = fma(-z[p][3], yb[k].y, fma(-z[p][2], yb[k].x, fma(-z[p][1], ya[k].y, fma(-z[p][0], ya[k].x, a[p][g + 1 + k]))));
+        }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < H; ++k)
+        if (g + 1 + H + k < 16) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                a[p][g + 1 + H + k] = fma(-z[p][3], yd[k].y, fma(-z[p][2], yd[k].x, fma(-z[p][1], yc[k].y, fma(-z[p][0], yc[k].x, a[p][g + 1 + H + k]))));
+        }
+}
+// The barrier sequence of potrf64<true> with the passenger rows one group behind the chain: group g's factor and finals are
+// in LDS after the chain's first barrier of round g; they are consumed here during round g + 1 (the finals are
+// double-buffered, the chain overwrites a buffer two rounds later).  On exit a[p][m] = X[row][4m + q] (scaled).
+template <int NP> __device__ __forceinline__ void potrf64_passengers(double (&a)[3][16], const double* sPY, const double* sF, const double* sRsq, const int q)
+{
+    lds_barrier(); // the panel of group 0 is published
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (g > 0 && NP > 0) passenger_group<NP>(a, g - 1, sPY, sF, q);
+        if (g == 15) break;
+        lds_barrier(); // finals of group g
+        lds_barrier(); // panel of group g + 1
+    }
+    lds_barrier(); // (pivots published) -- the factor of group 15 is there
+    if (NP > 0) passenger_group<NP>(a, 15, sPY, sF, q);
+    lds_barrier(); // 1 / sqrt(d) is there
+    if (NP > 0) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const double s = sRsq[4 * m + q];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p][m] *= s;
+        }
+    }
+}
+
+// ---- rank-64 update sub-tiles of the diagonal-block workgroup
+// acc[s] = X_t[16 r .., :] X_c[16 (s0 + s) .., :]^T, s < NS: pa -> T_t[16 r + lr][lk], pb -> T_c[16 s0 + lr][lk]; the operands
+// of the next four K steps are in flight while four are multiplied (one step ahead left the pipe waiting for LDS: 60 %).  (f64 16x16x4: a = A[lane & 15][lane >> 4], b = B[lane & 15][lane >> 4],
+// accumulator register reg = C[(lane >> 4) + 4 reg][lane & 15].)
+template <int NS> __device__ __forceinline__ void mfma_strip(const double* pa, const double* pb, double4_t (&acc)[4])
+{
+    constexpr int PD = 4; // K steps per operand chunk; chunk c + 1 is in flight while chunk c is multiplied
+    double av[2][PD], bv[2][NS][PD];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = (double4_t){ 0, 0, 0, 0 };
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+        av[0][j] = pa[4 * j];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bv[0][s][j] = pb[s * 16 * LDSP + 4 * j];
+    }
+#pragma unroll
+    for (int ch = 0; ch < NB / 4 / PD; ++ch) {
+        const int cur = ch & 1, nxt = cur ^ 1;
+        if (ch + 1 < NB / 4 / PD) {
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                av[nxt][j] = pa[4 * (PD * (ch + 1) + j)];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) bv[nxt][s][j] = pb[s * 16 * LDSP + 4 * (PD * (ch + 1) + j)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PD; ++j)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[cur][j], bv[cur][s][j], acc[s], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void mfma_strip_n(int ns, const double* pa, const double* pb, double4_t (&acc)[4])
+{
+    switch (ns) { // wave-uniform
+    case 1: mfma_strip<1>(pa, pb, acc); break;
+    case 2: mfma_strip<2>(pa, pb, acc); break;
+    case 3: mfma_strip<3>(pa, pb, acc); break;
+    default: mfma_strip<4>(pa, pb, acc); break;
+    }
+}
+
+struct StepDiag { // what the sub-steps of the diagonal-block workgroup share
+    double* sm;          // LDS
+    double* Ablk;        // A + k0 * ld + k0: the 256 x 256 diagonal block
+    int64_t ld;
+    unsigned* fl;
+    unsigned epoch;
+    int* info;
+    int z;
+    int64_t K;
+    unsigned hu[3][SRK_STEP_MAXHOLD]; // this wave's hold units of the three updates (wave-uniform: scalar registers)
+};
+
+// (test hook: a lost hand-off.  The counter was read by ONE lane when the workgroup started -- with two attempt slots in flight
+// another launch may change it between two lanes' reads -- into an LDS word the starting barrier published: nothing of it
+// is on the chain)
+__device__ __forceinline__ bool diag_fault(const StepDiag& S)
+{
+    return reinterpret_cast<const unsigned*>(S.sm + STP_CNT)[7] != 0;
+}
+
+// publication of L_DD and the X_tD (LDS tiles D .. 3 -> their places in A), write-through and coalesced (32 lanes store a whole
+// row of a tile), by NW waves of 64: thread tp of them takes rows (tp >> 5) + (NW * 2) k
+template <int D, int NW> __device__ __forceinline__ void diag_publish(const StepDiag& S, int tp)
+{
+    asm volatile("" : "+v"(tp)); // (opaque: no address of this is formed while potrf64 needs every register)
+    const int r = tp >> 5, c = (tp & 31) * 2;
+    const double* sT = S.sm + D * STP_TILE + r * LDSP + c;
+    double* G = S.Ablk + (int64_t)(D * NB + r) * S.ld + D * NB + c;
+#pragma unroll 1
+    for (int b = D; b < 4; ++b) {
+        // (all LDS reads of a tile first: the stores are asm statements with a memory clobber, nothing moves across them --
+        // read, wait, store, read, ... took 1.8 - 2.4 us to ISSUE four tiles)
+        double2 v[NB / (2 * NW)];
+#pragma unroll
+        for (int k = 0; k < NB / (2 * NW); ++k) v[k] = *reinterpret_cast<const double2*>(sT + 2 * NW * k * LDSP);
+#pragma unroll
+        for (int k = 0; k < NB / (2 * NW); ++k) {
+            st_store16(G, (dbl2_t){ v[k].x, v[k].y });
+            G += 2 * NW * S.ld;
+        }
+        sT += STP_TILE;
+    }
+}
+
+// U(D): the rank-64 updates of the NEXT PANEL's tiles (t, D + 1), t > D, by all eight waves (sub-tiles dealt out by
+// srk_step_tables.inc), then those tiles to LDS.  The tiles of the columns behind are the helper workgroups'.
+template <int D, bool CHAIN> __device__ __forceinline__ void diag_update(const StepDiag& S)
+{
+    constexpr int HS = D == 0 ? 4 : D == 1 ? 3 : 2;
+    int tid = threadIdx.x;
+    // (opaque: nothing that depends on the thread index -- table entries, tile addresses -- is formed before this point, i.e.
+    // while potrf64 needs every register)
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    double* const sm = S.sm;
+    const int64_t ld = S.ld;
+    const int64_t K = S.K; (void)K;
+    double4_t hacc[HS][2];
+    double hc[HS][2][4];
+    unsigned hu[HS];
+    // the tiles of block column D + 1 below its first one were updated with the X of the sub-steps before by the helper
+    // workgroups, long ago (a whole factorisation lies between): one poll, by every wave for itself (a workgroup barrier here
+    // would make the passenger waves wait for the chain waves) and before anything of this wave is in flight
+    if (D >= 1) st_wait_wave(S.fl, D == 1 ? (1u << ST_G(0)) | (1u << ST_G(1)) : 1u << ST_G(2), S.epoch, S.info);
+#pragma unroll
+    for (int h = 0; h < HS; ++h) {
+        const unsigned u = S.hu[D][h];
+        hu[h] = u;
+        const int t = u & 3, c = (u >> 2) & 3, r = (u >> 4) & 3, s0 = (u >> 6) & 3, ns = u >> 8;
+        // the tiles' values so far (this workgroup's own data: earlier launches or its own stores before the last barriers)
+        const double* pc = S.Ablk + (int64_t)(t * NB + 16 * r + lk) * ld + c * NB + 16 * s0 + lr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) hc[h][s][reg] = s < ns ? pc[(int64_t)(4 * reg) * ld + 16 * s] : 0.0;
+    }
+    SST(29 + D);
+#pragma unroll
+    for (int h = 0; h < HS; ++h) {
+        const unsigned u = hu[h];
+        const int t = u & 3, c = (u >> 2) & 3, r = (u >> 4) & 3, s0 = (u >> 6) & 3, ns = u >> 8;
+        double4_t acc[4];
+        acc[0] = acc[1] = (double4_t){ 0, 0, 0, 0 };
+        if (ns) { // wave-uniform
+            const double* pa = sm + t * STP_TILE + (16 * r + lr) * LDSP + lk;
+            const double* pb = sm + c * STP_TILE + (16 * s0 + lr) * LDSP + lk;
+            if (ns == 1) mfma_strip<1>(pa, pb, acc);
+            else mfma_strip<2>(pa, pb, acc);
+        }
+        hacc[h][0] = acc[0];
+        hacc[h][1] = acc[1];
+    }
+    SST(6 + 6 * D);
+    // publication: the chain waves issue the write-through stores of L_DD and the X_tD -- 128 KB at D = 0, which keep the CU's
+    // memory pipe busy for ~3 us: issued before the loads above they held every wave's loads back by 2 - 4 us, so they come
+    // BEHIND the chain waves' (small) share of the sub-tiles, while the passenger waves, which got the larger share for it
+    // (srk_step_tables.inc), are still multiplying.  They drain under the rest of this function; F(D) is set at its end.
+    if (CHAIN) diag_publish<D, 4>(S, tid);
+    SST(26 + D);
+    SST(4 + 6 * D);
+    lds_barrier(); // every wave is done multiplying: the X tiles are free
+    // the next panel's tiles to LDS (tile (D + 1, D + 1): zeros above the diagonal inside the sub-tiles on it; the sub-tiles
+    // above keep stale numbers -- potrf64 never reads above the diagonal)
+#pragma unroll
+    for (int h = 0; h < HS; ++h) {
+        const unsigned u = hu[h];
+        const int t = u & 3, r = (u >> 4) & 3, s0 = (u >> 6) & 3, ns = u >> 8;
+        double* pt = sm + t * STP_TILE + (16 * r + lk) * LDSP + 16 * s0 + lr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (s < ns) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int rr = 16 * r + lk + 4 * reg, cc = 16 * (s0 + s) + lr;
+                    pt[(4 * reg) * LDSP + 16 * s] = (t > D + 1 || cc <= rr) ? hc[h][s][reg] - hacc[h][s][reg] : 0.0;
+                }
+            }
+    }
+    lds_barrier();
+    if (CHAIN) { // the last chain wave to see its stores drained sets F(D)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            unsigned* sCnt = reinterpret_cast<unsigned*>(sm + STP_CNT);
+            const unsigned old = atomicAdd(&sCnt[D], 1u);
+            if (old == 3) __hip_atomic_store(S.fl + ST_F(D), S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    SST(5 + 6 * D);
+}
+
+// ---- the chain waves (0-3) of the diagonal-block workgroup, sub-step D
+template <int D> __device__ __forceinline__ bool diag_chain_substep(const StepDiag& S)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    double* const sm = S.sm;
+    double (*Td)[LDSP] = reinterpret_cast<double (*)[LDSP]>(sm + D * STP_TILE);
+    double* sInv = sm + STP_INV;
+    unsigned* sCnt = reinterpret_cast<unsigned*>(sm + STP_CNT);
+    const int64_t ld = S.ld;
+    const int64_t K = S.K; (void)K;
+    __builtin_amdgcn_s_setprio(3); // the chain's instructions before the passenger wave's of the same SIMD
+    const bool bad = potrf64<true>(Td, sm + STP_COL, sm + STP_DIAG, sInv, sm + STP_F, sm + STP_RSQ);
+    __builtin_amdgcn_s_setprio(0);
+    if (bad && tid == 0) atomicOr(S.info, 1);
+    SST(1 + 6 * D);
+    if (D == 0 && diag_fault(S)) return false;
+    // (the publication of L_DD and the X_tD is diag_update's first step; the last sub-step has no update: here)
+    if (D == 3) {
+        diag_publish<3, 4>(S, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const unsigned old = atomicAdd(&sCnt[D], 1u);
+            if (old == 3) __hip_atomic_store(S.fl + ST_F(D), S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SST(2 + 6 * D);
+    }
+    return true;
+}
+static __device__ __forceinline__ void diag_chain(const StepDiag& S)
+{
+    if (!diag_chain_substep<0>(S)) return;
+    diag_update<0, true>(S);
+    diag_chain_substep<1>(S);
+    diag_update<1, true>(S);
+    diag_chain_substep<2>(S);
+    diag_update<2, true>(S);
+    diag_chain_substep<3>(S);
+}
+
+// ---- the passenger waves (4-7), sub-step D: thread (i, q) carries row i of the tiles (t, D), t = D + 1 .. 3
+template <int D> __device__ __forceinline__ bool diag_passenger_substep(const StepDiag& S)
+{
+    constexpr int NP = 3 - D;
+    const int lt = threadIdx.x & 255, i = lt >> 2, q = lt & 3;
+    double* const sm = S.sm;
+    const int64_t K = S.K; (void)K;
+    double a[3][16];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { // (the initial load / the previous sub-step's update left the tiles in LDS)
+        const double (*Tt)[LDSP] = reinterpret_cast<const double (*)[LDSP]>(sm + (D + 1 + p) * STP_TILE);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) a[p][m] = Tt[i][4 * m + q];
+    }
+    potrf64_passengers<NP>(a, sm + STP_COL, sm + STP_F, sm + STP_RSQ, q);
+    // X_tD to LDS (the updates' operands) -- before the chain's last two barriers, like its own store of L_DD
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        double (*Tt)[LDSP] = reinterpret_cast<double (*)[LDSP]>(sm + (D + 1 + p) * STP_TILE);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Tt[i][4 * m + q] = a[p][m];
+    }
+    lds_barrier();
+    lds_barrier();
+    SST(1 + 6 * D);
+    if (D == 0 && diag_fault(S)) return false;
+    return true;
+}
+static __device__ __forceinline__ void diag_passengers(const StepDiag& S)
+{
+    if (!diag_passenger_substep<0>(S)) return;
+    diag_update<0, false>(S);
+    diag_passenger_substep<1>(S);
+    diag_update<1, false>(S);
+    diag_passenger_substep<2>(S);
+    diag_update<2, false>(S);
+    // (no rows are left below tile (3, 3): these waves end here, and the last factorisation's barriers count four waves)
+}
+
+__global__ __launch_bounds__(STP_THREADS) void k_step256(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
+                                                        int64_t K, unsigned* __restrict__ flags, unsigned epoch, int* __restrict__ info)
 {
     const int z = blockIdx.z;
     const int64_t row_end = rend.v[z];
@@ -659,46 +1066,155 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
     const int64_t ld = B.it[z].ld, k0 = K * NBO;
     unsigned* fl = flags + ST_WORDS * z;
     const int role = blockIdx.x, tid = threadIdx.x;
-    __shared__ __attribute__((aligned(16))) double sD[NB][NB + 2];
-    __shared__ __attribute__((aligned(16))) double sA[NB][NB + 2]; // own X of this sub-step (MFMA A operand); inverse role: sZ
-    // One region for the role-specific scratch: the inverse role's sT, or the other roles' potrf panel / finals, sInv and sy.
-    // (Round 3: with separate arrays the kernel held 83.7 KB of LDS -- 3 KB too much for TWO workgroups on a CU's 160 KB, so
-    // the ~416 workgroups of a speculative pair's two solves took turns on the 256 CUs instead of running side by side.)
-    __shared__ __attribute__((aligned(16))) double sU[32 * 33 > 14 * NB ? 32 * 33 : 14 * NB];
-    __shared__ double sDiag[NB];
-    double (*sT)[33] = reinterpret_cast<double (*)[33]>(sU);   // inverse role only
-    double* sCol = sU;                                         // [12 NB] potrf64: panel + two buffers of finals
-    double* sInv = sU + 12 * NB;                               // [NB]
-    double* sy = sU + 13 * NB;                                 // [NB]
-    static_assert(sizeof(double) * NB * (NB + 2) >= sizeof(double) * NB * (NB + 1), "sZ fits sA");
-    static_assert(2 * (2 * sizeof(double) * NB * (NB + 2) + sizeof(sU) + sizeof(double) * NB) <= 160 * 1024, "two workgroups per CU");
-    if (role == 4) { // ---- inverses of the diagonal tiles, as they are published
+    __shared__ __attribute__((aligned(16))) double sm[STP_LDS_DOUBLES];
+    SST(0);
+    if (role == 0) { // ---- the diagonal block
+        StepDiag S{ sm, A + k0 * ld + k0, ld, fl, epoch, info, z, K, {} };
+        {
+            const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int h = 0; h < SRK_STEP_MAXHOLD; ++h) S.hu[d][h] = c_step_hold[d][wave_s][h];
+        }
+        // block column 0 to LDS, coalesced: tile (0, 0) (zeros above its diagonal) and the passenger tiles (t, 0)
+        {
+            unsigned* sCnt = reinterpret_cast<unsigned*>(sm + STP_CNT);
+            if (tid < 7) sCnt[tid] = 0;
+            if (tid == 7) { // (test hook, see diag_fault)
+                int f = 0;
+                if (z == 0) {
+                    f = g_step_fault;
+                    if (f > 0) atomicSub(&g_step_fault, 1);
+                }
+                sCnt[7] = f > 0 ? 1u : 0u;
+            }
+            const int r = tid >> 3, cb = (tid & 7) * 8;
+            double2 v[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[b][k] = reinterpret_cast<const double2*>(S.Ablk + (int64_t)(b * NB + r) * ld + cb)[k];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = cb + 2 * k;
+                    double* dst = sm + b * STP_TILE + r * LDSP + c;
+                    dst[0] = (b > 0 || c <= r) ? v[b][k].x : 0.0;
+                    dst[1] = (b > 0 || c + 1 <= r) ? v[b][k].y : 0.0;
+                }
+        }
+        __syncthreads();
+        if (tid < 256)
+            diag_chain(S);
+        else
+            diag_passengers(S);
+        return;
+    }
+    double (*sD)[LDSP] = reinterpret_cast<double (*)[LDSP]>(sm);
+    double (*sA)[LDSP] = reinterpret_cast<double (*)[LDSP]>(sm + STP_TILE);
+    if (role == 1) { // ---- inverses of the diagonal tiles, as they are published
+        if (tid >= 256) return; // (tile_inverse is written for four waves)
+        double (*sT)[33] = reinterpret_cast<double (*)[33]>(sm + 2 * STP_TILE);
         for (int d = 0; d < NBO / NB; ++d) {
             st_wait(fl, 1u << ST_F(d), epoch, info);
             st_load_tile<true>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
             __syncthreads();
-            tile_inverse(sD, reinterpret_cast<double (*)[NB + 1]>(&sA[0][0]), sT, sDiag, B.it[z].dinv + (K * (NBO / NB) + d) * NB * NB);
+            tile_inverse(sD, reinterpret_cast<double (*)[NB + 1]>(&sA[0][0]), sT, sm + STP_DIAG, B.it[z].dinv + (K * (NBO / NB) + d) * NB * NB);
             __syncthreads();
         }
         return;
     }
-    int mytile;
+    if (role == 2) { // ---- forward substitution of the block's own rows: y_d = L_dd^-1 w_d (64 dependent steps on one wave,
+        // lane = row, its row of L in registers), published with flag Y(d); then w_t -= X_td y_d for the tile rows t > d below
+        if (tid >= 256) return;
+        double* sy = sm + STP_Y;
+        const int i = tid >> 2, q = tid & 3;
+        for (int d = 0; d < NBO / NB; ++d) {
+            const double wv = tid < NB ? w[k0 + d * NB + tid] : 0.0; // (this workgroup's own updates below, or earlier kernels)
+            st_wait(fl, 1u << ST_F(d), epoch, info);
+            st_load_tile<true>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
+            __syncthreads();
+            if (tid < NB) {
+                double Lr[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) Lr[j] = sD[tid][j];
+                const double myinv = fast_rcp(sD[tid][tid]);
+                double v = wv;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    v = tid == j ? v * myinv : v; // y_j, on lane j
+                    const double yj = readlane_f64(v, j);
+                    v = tid > j ? fma(-Lr[j], yj, v) : v;
+                }
+                sy[tid] = v;
+                st_store(y + k0 + d * NB + tid, v);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0) __hip_atomic_store(fl + ST_Y(d), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            for (int t = d + 1; t < NBO / NB; ++t) {
+                const int64_t row = k0 + t * NB + i;
+                const double* X = A + row * ld + k0 + d * NB;
+                double dot = 0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) dot = fma(X[4 * m + q], sy[4 * m + q], dot);
+                dot += __shfl_xor(dot, 1, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                if (q == 0) w[row] -= dot;
+            }
+            __syncthreads(); // (the w stores are complete before the next sub-step's load)
+        }
+        return;
+    }
+    if (role >= 3 && role < 6) { // ---- helper workgroups: the tiles of the diagonal block behind the next panel.  Helper k owns
+        // tile (t, c) = (2, 2), (3, 2), (3, 3) and applies C -= X_td X_cd^T for the sub-steps d <= c - 2 (the update of
+        // sub-step c - 1 is the diagonal-block workgroup's: by then the tile is the next panel); one tile of MFMA work each,
+        // with a whole factorisation of slack, then flag G(k)
+        const int hk = role - 3, t = hk == 0 ? 2 : 3, c = hk == 2 ? 3 : 2;
+        const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+        const int sr = wave >> 1, sc = (wave & 1) * 32; // a wave takes a 16 x 32 strip
+        double* Ablk = A + k0 * ld + k0;
+        double* pc0 = Ablk + (int64_t)(t * NB + 16 * sr + lk) * ld + c * NB + sc + lr;
+        for (int d = 0; d + 2 <= c; ++d) {
+            st_wait(fl, 1u << ST_F(d), epoch, info);
+            double cv[2][4];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) cv[n][reg] = pc0[(int64_t)(4 * reg) * ld + n * 16];
+            st_load_tile512(sD, Ablk + (int64_t)(t * NB) * ld + d * NB, ld);
+            if (t != c) st_load_tile512(sA, Ablk + (int64_t)(c * NB) * ld + d * NB, ld);
+            __syncthreads();
+            double4_t acc[4];
+            mfma_strip<2>(&sD[16 * sr + lr][lk], t != c ? &sA[sc + lr][lk] : &sD[sc + lr][lk], acc);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) st_store(pc0 + (int64_t)(4 * reg) * ld + n * 16, cv[n][reg] - acc[n][reg]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // (every wave has drained its stores; the LDS tiles are free)
+        }
+        if (tid == 0) __hip_atomic_store(fl + ST_G(hk), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ---- row workgroups
     int64_t r0;
-    if (role < 4) {
-        mytile = role;
-        r0 = k0 + role * NB;
-    } else {
+    {
         int64_t n1 = (row_end - (k0 + NBO)) / NB;
         if (n1 < 0) n1 = 0;
-        const int64_t r2_begin = r2b.v[z], n2 = (r2e.v[z] - r2_begin) / NB, ridx = role - 5;
+        const int64_t r2_begin = r2b.v[z], n2 = (r2e.v[z] - r2_begin) / NB, ridx = role - 6;
         if (ridx >= n1 + n2) return;
-        mytile = 4;
         r0 = ridx < n1 ? k0 + NBO + ridx * NB : r2_begin + (ridx - n1) * NB;
     }
-    const int i = tid >> 2, q = tid & 3;
+    double* sInv = sm + STP_INV;
+    double* sy = sm + STP_Y;
+    const bool sweeper = tid < 256; // waves 0-3 sweep (a row per quad); all eight waves multiply
+    const int i = (tid & 255) >> 2, q = tid & 3;
     double* rowp = A + (r0 + i) * ld + k0; // this thread's row, first column of the outer block
-    double wi = q == 0 ? w[r0 + i] : 0.0;
-    const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
+    double wi = (sweeper && q == 0) ? w[r0 + i] : 0.0;
+    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
     // forward substitution's update of this workgroup's rows with the PREVIOUS sub-step's panel, w_r -= X[r, tile p] . y_p:
     // y_p appears a few microseconds after L_pp, so its wait rides on the next wait this workgroup has anyway; X of the
     // previous sub-step is still in sA then
@@ -712,195 +1228,92 @@ __global__ __launch_bounds__(256, 2) void k_step256(const CholBatch B, const Cho
         dot += __shfl_xor(dot, 2, 64);
         wi -= dot;
     };
-    // a 64 x 64 tile from LDS to global memory, write-through and coalesced (a wave stores four whole rows at a time)
-    auto publish_tile = [&](const double (*sX)[NB + 2], double* T) {
-        const int r = tid >> 5, c = (tid & 31) * 2;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double2 v = *reinterpret_cast<const double2*>(&sX[r + 8 * k][c]);
-            st_store16(T + (int64_t)(r + 8 * k) * ld + c, (dbl2_t){ v.x, v.y });
-        }
-    };
-    SST(0);
     for (int d = 0; d < NBO / NB; ++d) {
-        if (d == mytile) {
-            SST(1 + 6 * d);
-            // ---- this workgroup's diagonal tile: every update has been applied (the last one went into sD)
-            if (d == 0) {
-                st_load_tile<true>(sD, A + r0 * ld + k0, ld);
-                __syncthreads();
-            }
-            const bool bad = potrf64(sD, sCol, sDiag, sInv);
-            SST(2 + 6 * d);
-            if (bad && tid == 0) atomicOr(info, 1);
-            publish_tile(sD, A + r0 * ld + k0 + d * NB);
-            if (d == 0 && z == 0) { // (test hook: a lost hand-off.  ONE lane reads the flag -- with two attempt slots in flight
-                // another launch may change it between two lanes' reads -- and the branch is workgroup-uniform)
-                if (tid == 0) {
-                    const int f = g_step_fault;
-                    if (f > 0) atomicSub(&g_step_fault, 1);
-                    sDiag[0] = f > 0 ? 1.0 : 0.0; // (sDiag is free here: potrf64 is done with it)
-                }
-                __syncthreads();
-                const bool fault = sDiag[0] != 0.0;
-                __syncthreads();
-                if (fault) return;
-            }
-            st_publish(fl + ST_F(d), epoch);
-            SST(3 + 6 * d);
-            if (d > 0) { // the pending update of w_d with y_(d-1)
-                st_wait(fl, 1u << ST_Y(d - 1), epoch, info);
-                w_update(d - 1);
-                __syncthreads(); // sy is rewritten next
-            }
-            // y_d = L_dd^-1 w_d: one wave, lane = row, 64 dependent steps
-            if (q == 0) sy[i] = wi;
-            __syncthreads();
-            if (tid < NB) {
-                double v = sy[tid];
-                const double myinv = sInv[tid];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    v = tid == j ? v * myinv : v; // y_j, on lane j
-                    const double yj = readlane_f64(v, j);
-                    v = tid > j ? fma(-sD[tid][j], yj, v) : v;
-                }
-                st_store(y + k0 + d * NB + tid, v);
-            }
-            st_publish(fl + ST_Y(d), epoch);
-            SST(4 + 6 * d);
-            return;
-        }
-        // ---- a sweeping sub-step (d < mytile): X = A[rows, tile d] L_dd^-T
         double a[16];
+        if (sweeper) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) a[m] = rowp[d * NB + 4 * m + q]; // own data (earlier kernels / this workgroup's updates)
+            for (int m = 0; m < 16; ++m) a[m] = rowp[d * NB + 4 * m + q]; // own data (earlier kernels / this workgroup's updates)
+        }
         SST(1 + 6 * d);
         st_wait(fl, (1u << ST_F(d)) | (d > 0 ? 1u << ST_Y(d - 1) : 0u), epoch, info);
         SST(2 + 6 * d);
         if (d > 0) w_update(d - 1);
-        st_load_tile<false>(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
+        st_load_tile512(sD, A + (k0 + d * NB) * ld + k0 + d * NB, ld);
         __syncthreads();
         if (tid < NB) sInv[tid] = fast_rcp(sD[tid][tid]);
         __syncthreads();
         SST(3 + 6 * d);
+        if (sweeper) {
+            // X = A[rows, tile d] L_dd^-T
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int c0 = 4 * b;
-            double v0 = quad_bcast<0>(a[b]), v1 = quad_bcast<1>(a[b]), v2 = quad_bcast<2>(a[b]), v3 = quad_bcast<3>(a[b]);
-            double x0 = v0 * sInv[c0];
-            double x1 = fma(-x0, sD[c0 + 1][c0], v1) * sInv[c0 + 1];
-            double x2 = fma(-x1, sD[c0 + 2][c0 + 1], fma(-x0, sD[c0 + 2][c0], v2)) * sInv[c0 + 2];
-            double x3 = fma(-x2, sD[c0 + 3][c0 + 2], fma(-x1, sD[c0 + 3][c0 + 1], fma(-x0, sD[c0 + 3][c0], v3))) * sInv[c0 + 3];
-            {
-                const double x01 = (q & 1) ? x1 : x0, x23 = (q & 1) ? x3 : x2;
-                a[b] = (q & 2) ? x23 : x01;
+            for (int b = 0; b < 16; ++b) {
+                const int c0 = 4 * b;
+                double v0 = quad_bcast<0>(a[b]), v1 = quad_bcast<1>(a[b]), v2 = quad_bcast<2>(a[b]), v3 = quad_bcast<3>(a[b]);
+                double x0 = v0 * sInv[c0];
+                double x1 = fma(-x0, sD[c0 + 1][c0], v1) * sInv[c0 + 1];
+                double x2 = fma(-x1, sD[c0 + 2][c0 + 1], fma(-x0, sD[c0 + 2][c0], v2)) * sInv[c0 + 2];
+                double x3 = fma(-x2, sD[c0 + 3][c0 + 2], fma(-x1, sD[c0 + 3][c0 + 1], fma(-x0, sD[c0 + 3][c0], v3))) * sInv[c0 + 3];
+                {
+                    const double x01 = (q & 1) ? x1 : x0, x23 = (q & 1) ? x3 : x2;
+                    a[b] = (q & 2) ? x23 : x01;
+                }
+#pragma unroll
+                for (int m = b + 1; m < 16; ++m) {
+                    const double2* lp = reinterpret_cast<const double2*>(&sD[4 * m + q][c0]);
+                    double2 l01 = lp[0], l23 = lp[1];
+                    a[m] = fma(-x3, l23.y, fma(-x2, l23.x, fma(-x1, l01.y, fma(-x0, l01.x, a[m]))));
+                    if (((m - b) & 3) == 0) asm volatile("" ::: "memory");
+                }
+                asm volatile("" ::: "memory");
             }
+            // X is final: to sA (the updates' A operand; the next w update reads it there) and to its place in A
 #pragma unroll
-            for (int m = b + 1; m < 16; ++m) {
-                const double2* lp = reinterpret_cast<const double2*>(&sD[4 * m + q][c0]);
-                double2 l01 = lp[0], l23 = lp[1];
-                a[m] = fma(-x3, l23.y, fma(-x2, l23.x, fma(-x1, l01.y, fma(-x0, l01.x, a[m]))));
-                if (((m - b) & 3) == 0) asm volatile("" ::: "memory");
-            }
-            asm volatile("" ::: "memory");
-        }
-        SST(4 + 6 * d);
-        // X is final: to sA (the updates' A operand; the next w update reads it there) and to its place in A -- a diagonal
-        // workgroup publishes it (coalesced, from sA), a row workgroup stores it plainly
-#pragma unroll
-        for (int m = 0; m < 16; ++m) sA[i][4 * m + q] = a[m];
-        const int tmax = mytile < 4 ? mytile : NBO / NB - 1;
-        unsigned need = 0;
-        for (int t = d + 1; t <= tmax; ++t)
-            if (t != mytile) need |= 1u << ST_G(t, d);
-        if (mytile < 4) {
-            __syncthreads();
-            publish_tile(sA, A + r0 * ld + k0 + d * NB);
-            st_publish(fl + ST_G(mytile, d), epoch);
-        } else {
+            for (int m = 0; m < 16; ++m) sA[i][4 * m + q] = a[m];
 #pragma unroll
             for (int m = 0; m < 16; ++m) rowp[d * NB + 4 * m + q] = a[m];
         }
-        SST(5 + 6 * d);
-        if (need) st_wait(fl, need, epoch, info);
-        else __syncthreads(); // sA is written; every wave is done with L_dd in sD
-        SST(6 + 6 * d);
-        // rank-64 update of this workgroup's tiles (., t), t = d + 1 .. tmax:  C -= X X_td^T.  The B operand X_td of the next
-        // tile is fetched into registers while this one is multiplied.
-        const int bi = tid >> 2, bc = (tid & 3) * 16;
-        double2 bv[8];
+        SST(4 + 6 * d);
+        // rank-64 update of this workgroup's tiles (., t), t = d + 1 .. 3:  C -= X X_td^T.  The B operand X_td (published with
+        // L_dd) goes through two LDS buffers; the next one is fetched into registers while this one is multiplied.  A wave
+        // takes a 16 x 32 strip of the 64 x 64 tile.
+        const int bi = tid >> 3, bc = (tid & 7) * 8;
+        double2 bv[4];
         auto fetch_b = [&](int t) {
             const double2* src = reinterpret_cast<const double2*>(A + (k0 + t * NB + bi) * ld + k0 + d * NB + bc);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) bv[k] = src[k];
+            for (int k = 0; k < 4; ++k) bv[k] = src[k];
         };
-        if (d + 1 <= tmax && d + 1 != mytile) fetch_b(d + 1);
-        for (int t = d + 1; t <= tmax; ++t) {
-            const bool own = t == mytile;               // the diagonal tile of a diagonal workgroup: B operand = its own X
-            const bool to_lds = own && d + 1 == mytile; // its last update: the result is what potrf64 factors next
-            double (*sB)[NB + 2] = own ? sA : sD;
-            double* pc0 = A + (r0 + wr * 32 + lk) * ld + k0 + t * NB + wc * 32 + lr;
-            double cv[2][2][4];
+        if (d + 1 < NBO / NB) fetch_b(d + 1);
+        const int sr = wave >> 1, sc = (wave & 1) * 32;
+        for (int t = d + 1; t < NBO / NB; ++t) {
+            double (*sB)[LDSP] = reinterpret_cast<double (*)[LDSP]>(sm + (2 + ((t - d - 1) & 1)) * STP_TILE);
+            double* pc0 = A + (r0 + 16 * sr + lk) * ld + k0 + t * NB + sc + lr;
+            double cv[2][4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int reg = 0; reg < 4; ++reg) cv[n][reg] = pc0[(int64_t)(4 * reg) * ld + n * 16];
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) cv[m][n][reg] = pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16];
-            if (!own) {
-                if (t > d + 1) __syncthreads(); // every wave is done with the previous B tile in sD
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    sD[bi][bc + 2 * k] = bv[k].x;
-                    sD[bi][bc + 2 * k + 1] = bv[k].y;
-                }
-                __syncthreads();
-                if (t + 1 <= tmax && t + 1 != mytile) fetch_b(t + 1);
+            for (int k = 0; k < 4; ++k) {
+                sB[bi][bc + 2 * k] = bv[k].x;
+                sB[bi][bc + 2 * k + 1] = bv[k].y;
             }
-            double4_t acc[2][2];
+            __syncthreads(); // (also: sA is written; every wave is done with the buffer of two tiles ago)
+            if (t + 1 < NBO / NB) fetch_b(t + 1);
+            double4_t acc[4];
+            mfma_strip<2>(&sA[16 * sr + lr][lk], &sB[sc + lr][lk], acc);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = (double4_t){ 0, 0, 0, 0 };
-#pragma unroll
-            for (int kk = 0; kk < NB / 4; ++kk) {
-                const double a0 = sA[wr * 32 + lr][kk * 4 + lk];
-                const double a1 = sA[wr * 32 + 16 + lr][kk * 4 + lk];
-                const double b0 = sB[wc * 32 + lr][kk * 4 + lk];
-                const double b1 = sB[wc * 32 + 16 + lr][kk * 4 + lk];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-            }
-            if (to_lds) {
-                __syncthreads(); // (a slower wave may still read the previous B tile in sD)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int rr = wr * 32 + m * 16 + 4 * reg + lk, cc = wc * 32 + n * 16 + lr;
-                            sD[rr][cc] = cc <= rr ? cv[m][n][reg] - acc[m][n][reg] : 0.0;
-                        }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(m * 16 + 4 * reg) * ld + n * 16] = cv[m][n][reg] - acc[m][n][reg];
-            }
+                for (int reg = 0; reg < 4; ++reg) pc0[(int64_t)(4 * reg) * ld + n * 16] = cv[n][reg] - acc[n][reg];
         }
-        __syncthreads(); // the updates' stores are complete before the next sub-step loads its columns; sD is free
+        __syncthreads(); // the updates' stores are complete before the next sub-step loads its columns; sD, sA are free
+        SST(5 + 6 * d);
     }
-    // (row workgroups only; a diagonal workgroup's w_t became y_t)
     st_wait(fl, 1u << ST_Y(NBO / NB - 1), epoch, info);
     w_update(NBO / NB - 1);
     SST(25);
-    if (q == 0) w[r0 + i] = wi;
+    if (sweeper && q == 0) w[r0 + i] = wi;
 }
 
 // ---------------------------------------------------------------- trailing update of an outer panel (MFMA, K = 256)
@@ -1286,12 +1699,11 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
             if (n1 < 0) n1 = 0;
             row_wgs = std::max(row_wgs, n1 + (r2e.v[i] - r2b.v[i]) / NB);
         }
-        const bool fused = sync && sync->flags && sync->fused && (5 + row_wgs) * n <= 256;
+        const bool fused = sync && sync->flags && sync->fused && (6 + row_wgs) * n <= 256;
         if (fused) {
             ++sync->epoch;
             if (sync->epoch == 0) ++sync->epoch; // the flag words start at 0
-            static const unsigned pad_lds = getenv("SRK_STEP_PAD_LDS") ? 8192u : 0u; // development: one workgroup per CU again
-            LAUNCH(k_step256, dim3((unsigned)(5 + row_wgs), 1, (unsigned)n), dim3(256), pad_lds, s, B, st, r2b, r2e, K, sync->flags,
+            LAUNCH(k_step256, dim3((unsigned)(6 + row_wgs), 1, (unsigned)n), dim3(STP_THREADS), 0, s, B, st, r2b, r2e, K, sync->flags,
                    sync->epoch, d_info);
         }
         for (int jsub = 0; jsub < NBO / NB && !fused; ++jsub) {

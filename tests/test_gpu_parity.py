@@ -1160,11 +1160,12 @@ def test_nested_plan_edge_sizes(gpu, n_frames):
     assert rel_err(dc, x) < 1e-9, (n_frames, gpu.rcs_chunks())
 
 
-def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_dense(gpu):
-    """k_step256 (an outer step of the blocked Cholesky as ONE launch whose workgroups hand tiles to one another) against
-    the k_panel / k_upd64 launch sequence it replaces: same arithmetic in the same order, so the solutions must be
-    IDENTICAL.  Dense systems of one to five outer steps; repeated, so that a stale read of a handed-off tile would have
-    several chances to show."""
+def test_fused_outer_step_is_reproducible_and_agrees_with_the_panel_sequence_dense(gpu):
+    """k_step256 (an outer step of the blocked Cholesky as ONE launch: a diagonal-block workgroup that owns the 256 x 256
+    block for all four sub-steps and hands L and X tiles one way to row workgroups) against the k_panel / k_upd64 launch
+    sequence it replaces.  Same factorisation, but the block's own rows are eliminated in potrf64's unscaled form (round 4), so
+    the two agree to rounding; the fused solve must be IDENTICAL from run to run (no atomics, fixed summation order; repeated,
+    so that a stale read of a handed-off tile would have several chances to show).  Dense systems of one to five outer steps."""
     rng = np.random.RandomState(5)
     try:
         for n in (200, 256, 300, 777, 1280):
@@ -1179,17 +1180,19 @@ def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_dense(gpu):
                 if fused in sols:
                     assert np.array_equal(x, sols[fused]), n
                 sols[fused] = x
-            assert np.array_equal(sols[1], sols[0]), n
-            assert np.abs(sols[1] - np.linalg.solve(A, b)).max() < 1e-10 * max(1.0, np.abs(x).max())
+            ref = np.linalg.solve(A, b)
+            assert np.abs(sols[1] - sols[0]).max() < 1e-13 * max(1.0, np.abs(ref).max()), n
+            assert np.abs(sols[1] - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
         assert gpu.solver_sync_timeouts() == 0
     finally:
         gpu.set_solver_fusion(1)
 
 
 @pytest.mark.parametrize("n_frames,window", [(103, 8), (330, 8), (500, 30), (800, 95)])
-def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_frames, window):
+def test_fused_outer_step_is_reproducible_and_agrees_with_the_panel_sequence_chunked(gpu, n_frames, window):
     """The same on nested chunks with 256- to 1024-wide separators (batched items, border rows, structurally zero border
-    rows skipped per step): the chunked solve works on copies, so the SAME reduced camera system is solved both ways."""
+    rows skipped per step): the chunked solve works on copies, so the SAME reduced camera system is solved both ways; both
+    must be as close to the exact solution of that system as a backward-stable factorisation gets."""
     spec = sa.SceneSpec(n_frames=n_frames, grid_nx=60, grid_ny=40, vis_window=window)
     sc = sa.generate_scene(spec)
     try:
@@ -1197,6 +1200,8 @@ def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_f
         assert gpu.rcs_chunks() >= 2
         gpu.phase_derivatives()
         gpu.phase_schur(1e-3)
+        S = gpu.buffer(B.BUF_RCS).reshape(10 * n_frames, 10 * n_frames)
+        rhs = gpu.buffer(B.BUF_RCS_RHS)
         sols = {}
         for fused in (1, 0, 1, 1, 1):
             gpu.set_solver_fusion(fused)
@@ -1206,7 +1211,11 @@ def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_f
             if fused in sols:
                 assert np.array_equal(x, sols[fused])
             sols[fused] = x
-        assert np.array_equal(sols[1], sols[0])
+        ref = np.linalg.solve(S, rhs)
+        for _ in range(3):
+            ref = ref + np.linalg.solve(S, rhs - S @ ref)
+        assert rel_err(sols[1], ref) < 1e-9 and rel_err(sols[0], ref) < 1e-9
+        assert rel_err(sols[1], sols[0]) < 1e-9
         assert gpu.solver_sync_timeouts() == 0
     finally:
         gpu.set_solver_fusion(1)
@@ -1215,7 +1224,8 @@ def test_fused_outer_step_equals_the_panel_sequence_bit_for_bit_chunked(gpu, n_f
 def test_fused_solve_hand_offs_stay_exact_beside_a_streaming_load():
     """tools/stress_fused.py in small: the bench scene's reduced camera system solved 60 times with the fused outer
     step while another stream keeps HBM busy (uneven load, consumer caches warm from the previous solve); every solution
-    must equal the unfused sequence's bit for bit and no hand-off may time out."""
+    must equal the first one bit for bit (a stale read of a handed-off tile would differ), agree with the unfused sequence's
+    to rounding, and no hand-off may time out."""
     import torch
     spec = sa.CONFIGS["C3_1kcam_100kpt"]
     sc = sa.generate_scene(spec)
@@ -1227,8 +1237,11 @@ def test_fused_solve_hand_offs_stay_exact_beside_a_streaming_load():
         h.phase_schur(1e-3)
         h.set_solver_fusion(0)
         assert h.phase_solve()
-        ref = h.buffer(B.BUF_CORRECTIONS)[3 * sc.N:].copy()
+        unfused = h.buffer(B.BUF_CORRECTIONS)[3 * sc.N:].copy()
         h.set_solver_fusion(1)
+        assert h.phase_solve()
+        ref = h.buffer(B.BUF_CORRECTIONS)[3 * sc.N:].copy()
+        assert rel_err(ref, unfused) < 1e-9
         side = torch.cuda.Stream()
         x = torch.empty(32 * 1024 * 1024, device="cuda", dtype=torch.float64)
         y = torch.empty_like(x)
@@ -1304,7 +1317,7 @@ def test_a_lost_hand_off_in_the_staged_solve_calls_is_repeated_unfused(gpu):
         sa.lib().srk_dbg_step_fault(1)
         assert gpu.phase_solve()                      # timed out inside, repeated unfused, succeeded
         assert gpu.solver_sync_timeouts() == before + 1
-        assert np.array_equal(gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:], ref)   # fused and unfused sequences agree bit for bit
+        assert rel_err(gpu.buffer(B.BUF_CORRECTIONS)[3 * sc.N:], ref) < 1e-9   # fused and unfused sequences agree to rounding
         gpu.set_solver_fusion(1)
         rng = np.random.RandomState(5)
         A = rng.randn(300, 300)

@@ -15,13 +15,21 @@ for _ in range(2):
 out=(C.c_longlong*256)()
 sa.lib().srk_dbg_step_stamps(out)
 st=np.array(list(out)).reshape(8,32)
-t0=st[:, 0].min()
-names={0:"start",25:"end"}
-for d in range(4):
-    names.update({1+6*d:f"d{d} begin",2+6*d:f"d{d} L here/potrf",3+6*d:f"d{d} L loaded/F pub",4+6*d:f"d{d} swept/Y pub",5+6*d:f"d{d} X pub",6+6*d:f"d{d} need here"})
+t0=st[:, 0][st[:, 0] > 0].min()
+rows={0:"diag chain",1:"diag passengers",2:"inverse",3:"inverse (idle half)",4:"forward",5:"forward (idle half)",6:"helper (2,2)",7:"helper (2,2) (waves 4-7)"}
+diag={0:"start",1:"potrf/passengers done",2:"F published",3:"Y published",4:"drained, F set",5:"update done"}
+roww={0:"start",1:"begin",2:"flags seen",3:"L loaded",4:"swept",5:"updates done"}
 print("k_step256, item 0, outer step 0 (LAST launch with K == 0 = last level of the last solve); us since the first workgroup's start")
 for r in range(8):
-    row=[(k, (st[r,k]-t0)/100.0) for k in range(26) if st[r,k]>0]
-    print("role", r, " ".join(f"[{names.get(k,k)}] {v:.1f}" for k,v in row))
+    names = diag if r < 2 else roww
+    row=sorted([(k, (st[r,k]-t0)/100.0) for k in range(32) if st[r,k]>0], key=lambda x: x[1])
+    def nm(k):
+        if k == 0: return "start"
+        if k == 25: return "end"
+        if r < 2 and 26 <= k <= 28: return "d%d stores issued" % (k - 26)
+        if r < 2 and 29 <= k <= 31: return "d%d G seen, C loads issued" % (k - 29)
+        if r < 2 and k % 6 == 0: return "d%d mfma issued" % (k // 6 - 1)
+        return "d%d %s" % ((k-1)//6, names.get((k-1)%6+1, k))
+    print(rows[r], " ".join(f"[{nm(k)}] {v:.1f}" for k,v in row))
 PY
 )
