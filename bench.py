@@ -340,10 +340,8 @@ def main():
 
             id1 = new_id()
             native_step("srk_ba_rccl_init", lambda: ba.rccl_init(id1, rank, world))
-            sched = os.environ.get("SRK_MULTI_SCHEDULE", "dp")
-            exchange = ("native RCCL, damping-parallel schedule: band k reduced to rank k, corrections broadcast, one all-reduce of "
-                        "the status words; one communicator on the library's collective stream") if sched != "allreduce" else \
-                       "native RCCL all-reduce of the band on the attempt's stream (round-2 schedule)"
+            ba.set_multi_schedule(os.environ.get("SRK_BENCH_SCHEDULE", "dp"))  # "dp" (default) or "allreduce"
+            exchange = "native RCCL"
         else:
             from surikatoko_amd.dist import make_allreduce_hook
             ba.set_allreduce(make_allreduce_hook(None, f"cuda:{local_rank}"), rank, world)
@@ -389,6 +387,16 @@ def main():
     iterations = ba.report.iterations
     attempts_timed = ba.report.attempts
     iter_log = ba.iteration_log()
+    # the exchange schedule that actually ran: the first native damping-parallel round of a handle checks itself (checksums
+    # beside the rooted collectives) and the handle falls back to the all-reduce schedule when that fails
+    schedule_used = ba.multi_schedule() if world > 1 else "none"
+    if world > 1 and exchange == "native RCCL":
+        exchange = {"dp": "native RCCL, damping-parallel schedule (no native round ran)",
+                    "dp (self-check passed)": "native RCCL, damping-parallel schedule: band k reduced to rank k, corrections "
+                                              "broadcast, one all-reduce of the status words; first round self-checked",
+                    "allreduce": "native RCCL all-reduce of the band on the attempt's stream (round-2 schedule)",
+                    "allreduce (dp self-check failed)": "native RCCL all-reduce schedule AFTER the damping-parallel round failed its "
+                                                        "self-check: " + ba.last_error()[:200]}[schedule_used]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -653,8 +661,10 @@ def main():
                           "step": "one accepted outer LM iteration with its rejected attempts, one continuing run",
                           "parallelism": out["config"]["parallelism"], "exchange": exchange, "rcs_solver": args.rcs,
                           "rcs_chunks": rcs_chunks,
-                          "lm_attempts": ("sequential" if args.sequential_attempts else
-                                          ("speculative pairs" if world == 1 else f"{min(3, world)} damping factors a round, one per rank"))}
+                          "schedule": schedule_used,
+                          "lm_attempts": ("sequential" if args.sequential_attempts and world == 1 else
+                                          ("speculative pairs" if world == 1 or not schedule_used.startswith("dp") else
+                                           f"{min(3, world)} damping factors a round, one per rank"))}
         line.update({"iterations_done": iterations, "attempts": int(attempts_timed),
                      "converging_phase": None if converging is None else {k: converging[k] for k in ("iterations", "attempts", "iterations_per_s")},
                      "attempts_per_s": out["attempts_per_s"],

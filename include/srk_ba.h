@@ -275,6 +275,21 @@ int64_t srk_ba_iteration_log(srk_ba*, int64_t cap, int32_t* attempts, double* ms
  * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time. */
 int srk_ba_set_speculation(srk_ba*, int on);
 
+/* Exchange schedule of the LM loop with several ranks (landmark shards; takes effect at the next upload):
+ *   1 (default) damping-parallel: a round builds the next min(3, world) damping factors c, 10c, 100c on every shard, band k is
+ *     REDUCED to rank k, rank k solves factor k and broadcasts its corrections, every rank scores all of them and one
+ *     all-reduce carries the status words -- an iteration that needs <= 3 attempts costs about one solve;
+ *   0 all-reduce: the band of each attempt is all-reduced and every rank solves the same system redundantly (round 2);
+ *   2 the damping-parallel schedule at world size 1 as well (rehearsal of its collectives on one GPU).
+ * The native (RCCL) form of schedule 1 issues groups of ncclReduce / ncclBroadcast rooted at different ranks on one
+ * communicator.  Its FIRST round on a handle checks itself: checksums of every band and of every corrections vector travel
+ * beside the rooted collectives through plain all-reduces; on a mismatch or an RCCL error the handle switches to schedule 0
+ * for good, the round is repeated that way and srk_ba_last_error says why.
+ * srk_ba_multi_schedule: 0 all-reduce (asked for), 1 damping-parallel (no native round has run yet), 2 damping-parallel
+ * with its self-check passed, 3 all-reduce after a failed self-check. */
+int srk_ba_set_multi_schedule(srk_ba*, int mode);
+int srk_ba_multi_schedule(srk_ba*);
+
 /* Internal frame order.  The reference's dense solve (bundle-adj-kanatani.cpp:1911) does not care how the frames are
  * numbered; the skyline solver, its nested dissection and the derivative kernels' frame windows here want covisible frames
  * to have nearby indices.  When the caller's numbering is far from banded (an unordered image set, a sequence that closes

@@ -293,6 +293,17 @@ class BundleAdjustmentKanatani:
         """Run the next damping factor beside the current attempt (one rank, instrumentation off); next upload."""
         self._raise(self._lib.srk_ba_set_speculation(C.c_void_p(self._h), C.c_int(int(bool(on)))))
 
+    MULTI_SCHEDULES = {"allreduce": 0, "dp": 1, "dp_force": 2}
+
+    def set_multi_schedule(self, schedule="dp"):
+        """exchange schedule with several ranks (srk_ba_set_multi_schedule): "dp" (default), "allreduce", "dp_force"; before upload"""
+        self._raise(self._lib.srk_ba_set_multi_schedule(C.c_void_p(self._h), C.c_int(self.MULTI_SCHEDULES[schedule])))
+
+    def multi_schedule(self):
+        """schedule in effect (srk_ba_multi_schedule): 'allreduce', 'dp', 'dp (self-check passed)', 'allreduce (dp self-check failed)'"""
+        return {0: "allreduce", 1: "dp", 2: "dp (self-check passed)", 3: "allreduce (dp self-check failed)"}[
+            int(self._lib.srk_ba_multi_schedule(C.c_void_p(self._h)))]
+
     def set_frame_reordering(self, mode=-1):
         """-1 automatic, 0 = keep the caller's frame order, 1 = renumber whenever the ordering differs (next upload)"""
         self._raise(self._lib.srk_ba_set_frame_reordering(C.c_void_p(self._h), C.c_int(mode)))

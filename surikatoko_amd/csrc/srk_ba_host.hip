@@ -133,9 +133,15 @@ struct srk_ba {
     // Damping-parallel schedule (world >= 2): an iteration's attempts c, 10c, 100c are built by every rank on its
     // shard, band k is REDUCED to rank k, rank k solves factor k and broadcasts its corrections, every rank scores all of
     // them.  All collectives of that schedule go through ONE communicator on ONE stream (comm_stream) in one program order.
-    bool dp_schedule = true;          // SRK_MULTI_SCHEDULE=allreduce: the round-2 schedule (all-reduce, redundant solves)
-    bool dp_force = false;            // SRK_MULTI_SCHEDULE=dp_force: the schedule at world size 1 as well (three slots, every
+    bool dp_schedule = true;          // srk_ba_set_multi_schedule(h, 0): the round-2 schedule (all-reduce, redundant solves)
+    bool dp_force = false;            // srk_ba_set_multi_schedule(h, 2): the schedule at world size 1 as well (three slots, every
                                       // collective issued; all one GPU can rehearse of the native path)
+    // The native form of that schedule (groups of ncclReduce / ncclBroadcast rooted at different ranks on one communicator)
+    // has never run on more than one GPU in this repository's tests: its FIRST round on a handle checks itself against plain
+    // all-reduces of checksums (dp_selfcheck below); a mismatch or an RCCL error switches the handle to the all-reduce schedule.
+    bool dp_verified = false;         // the first native round passed its self-check
+    bool dp_selfcheck_failed = false; // ... or did not: the handle runs the all-reduce schedule (srk_ba_multi_schedule: 3)
+    DevBuf dp_chk;                    // scratch of the self-check: [512] partial sums, [2] checksum, [16] all-reduce staging
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_comm = nullptr;
     DevBuf status_all;                // [SRK_SLOTS][8] doubles: the slots' {error, solver info, point-update info}
@@ -275,12 +281,14 @@ srk_ba* srk_ba_create(int device_id)
         return nullptr;
     }
     h->main_stream = h->stream;
-    if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = h->chol_fused_wanted = e[0] != '0'; // development: the unfused launch sequence
+#ifdef SRK_DEV // development switches (tools/): the default build reads no environment but SRK_DEBUG (the trace)
+    if (const char* e = getenv("SRK_CHOL_FUSED")) h->chol_fused = h->chol_fused_wanted = e[0] != '0'; // the unfused launch sequence
     if (const char* e = getenv("SRK_MULTI_SPECULATION")) h->spec_multi = e[0] != '0';
     if (const char* e = getenv("SRK_MULTI_SCHEDULE")) {
         h->dp_schedule = std::strcmp(e, "allreduce") != 0;
         h->dp_force = std::strcmp(e, "dp_force") == 0;
     }
+#endif
     h->att[0].stream = h->stream;
     bool ok = hipEventCreateWithFlags(&h->ev_jac, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming) == hipSuccess &&
@@ -1124,7 +1132,12 @@ extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double
     // work item per pair of blocks (k_schur_long).  A track over more frames than a run holds keeps the per-landmark kernel.
     std::vector<int32_t> lg_item, lg_np, lg_nf, lg_pts, lg_frames, lg_obs;
     std::vector<int64_t> lg_obs_off;
-    if (getenv("SRK_SCHUR_NO_LONG")) { // development: everything through the per-landmark kernel
+#ifdef SRK_DEV
+    const bool no_long = getenv("SRK_SCHUR_NO_LONG") != nullptr; // development: everything through the per-landmark kernel
+#else
+    const bool no_long = false;
+#endif
+    if (no_long) {
         gen_list.insert(gen_list.end(), long_cand.begin(), long_cand.end());
         long_cand.clear();
     }
@@ -1599,6 +1612,35 @@ static int exchange(srk_ba* h, double* dev_ptr, int64_t count)
 // (gloo rehearsals, a caller's own transport) only a sum is available: a reduce is an all-reduce whose result the other
 // ranks ignore, a broadcast an all-reduce of a buffer the other ranks zeroed; the callback blocks the host.
 enum { SRK_COLL_ALLREDUCE = 0, SRK_COLL_REDUCE = 1, SRK_COLL_BCAST = 2 };
+#define SRK_RETRY_ALLREDUCE 1000 // (internal) the damping-parallel round failed its self-check: the all-reduce schedule from here on
+#ifdef SRK_DEV
+static int g_dp_corrupt = 0; // test hook: the next self-check finds a mismatch at stage 1 (reduce) / 2 (broadcast)
+extern "C" void srk_dbg_dp_corrupt(int stage) { g_dp_corrupt = stage; }
+#endif
+// {sum, sum of magnitudes} of a device buffer in a fixed order, to the host (blocking: first round of a handle only)
+static int dp_checksum(srk_ba* h, hipStream_t st, const double* p, int64_t n, double out[2])
+{
+    int rc = dev_alloc(h, h->dp_chk, 8 * (512 + 2 + 16));
+    if (rc != SRK_OK) return rc;
+    srk_launch_checksum(st, p, n, P<double>(h->dp_chk), P<double>(h->dp_chk) + 512);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, P<double>(h->dp_chk) + 512, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return SRK_OK;
+}
+// sum over the ranks of n <= 16 host doubles through the communicator's plain all-reduce (blocking)
+static int dp_allreduce_host(srk_ba* h, double* v, int n)
+{
+    int rc = dev_alloc(h, h->dp_chk, 8 * (512 + 2 + 16));
+    if (rc != SRK_OK) return rc;
+    double* stage = P<double>(h->dp_chk) + 514;
+    HIPCHK(h, hipMemcpyAsync(stage, v, (size_t)(8 * n), hipMemcpyHostToDevice, h->comm_stream));
+    ncclResult_t r = rccl().AllReduce(stage, stage, (size_t)n, ncclDouble, ncclSum, h->comm, h->comm_stream);
+    if (r != ncclSuccess) { h->last_error = std::string("ncclAllReduce (self-check): ") + rccl().GetErrorString(r); return SRK_E_DEVICE; }
+    HIPCHK(h, hipMemcpyAsync(v, stage, (size_t)(8 * n), hipMemcpyDeviceToHost, h->comm_stream));
+    HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+    return SRK_OK;
+}
 static int coll_group(srk_ba* h, int op, int G, double* const* ptrs, const int64_t* counts)
 {
     if (h->comm) {
@@ -2041,8 +2083,8 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
             return r2;
         };
         // several ranks, damping-parallel schedule (instrumentation off): see dp_round below
-        const bool dp_mode = (h->allreduce || h->comm) && (h->world >= 2 || h->dp_force) && h->dp_schedule &&
-                             h->profile_level == 0 && h->att[1].allocated;
+        bool dp_mode = (h->allreduce || h->comm) && (h->world >= 2 || h->dp_force) && h->dp_schedule &&
+                       h->profile_level == 0 && h->att[1].allocated;
         // wait for slot sl's attempt and judge it exactly as the reference judges the attempt with factor `hessian_factor`
         std::function<int(int, double)> redo_unfused; // (defined below: repeats one attempt after a hand-off timeout)
         auto judge_attempt = [&](int sl) -> int {
@@ -2132,7 +2174,36 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
                 counts[k] = h->band_packed + d.ld;
             }
             select_attempt(h, 0);
+            // first native round of this handle: every rooted collective is checked against a plain all-reduce of checksums
+            const bool verify = h->comm != nullptr && !h->dp_verified;
+            double expect[2 * SRK_SLOTS] = {}, bad = 0;
+            auto selfcheck_failed = [&](const char* what) {
+                h->dp_schedule = false;
+                h->dp_selfcheck_failed = true;
+                h->last_error = std::string("damping-parallel schedule: self-check of the first native round failed (") + what +
+                                "); this handle runs the all-reduce schedule";
+                if (srk_debug()) fprintf(stderr, "srk_ba[rank %d]: %s\n", h->rank, h->last_error.c_str());
+                return SRK_RETRY_ALLREDUCE;
+            };
+            if (verify && r2 == SRK_OK) { // what the sum over the ranks of band k must be
+                for (int k = 0; k < G && r2 == SRK_OK; ++k) r2 = dp_checksum(h, h->att[k].stream, ptrs[k], counts[k], expect + 2 * k);
+                if (r2 == SRK_OK) r2 = dp_allreduce_host(h, expect, 2 * G);
+            }
             if (r2 == SRK_OK) r2 = coll_group(h, SRK_COLL_REDUCE, G, ptrs, counts);
+            if (verify) {
+                if (r2 == SRK_E_DEVICE) return selfcheck_failed("an RCCL call of the reduce group returned an error");
+                for (int k = 0; k < G && r2 == SRK_OK; ++k) {
+                    if (h->rank != k % h->world) continue;
+                    double got[2];
+                    r2 = dp_checksum(h, h->att[k].stream, ptrs[k], counts[k], got); // (the slot's stream waits for the group)
+                    if (!(std::fabs(got[0] - expect[2 * k]) <= 1e-9 * expect[2 * k + 1] + 1e-300)) bad += 1;
+                }
+#ifdef SRK_DEV
+                if (g_dp_corrupt == 1) bad += 1, g_dp_corrupt = 0;
+#endif
+                if (r2 == SRK_OK) r2 = dp_allreduce_host(h, &bad, 1);
+                if (r2 == SRK_OK && bad > 0) return selfcheck_failed("a reduced band does not sum to the all-reduced checksum");
+            }
             for (int k = 0; k < G && r2 == SRK_OK; ++k) {
                 select_attempt(h, k);
                 if (h->rank == k % h->world) {
@@ -2143,7 +2214,30 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
                 counts[k] = d.ld;
             }
             select_attempt(h, 0);
+            double rootv[2 * SRK_SLOTS] = {};
+            if (verify && r2 == SRK_OK) { // the checksum of the corrections on the rank that solved them, known to everybody
+                for (int k = 0; k < G && r2 == SRK_OK; ++k)
+                    if (h->rank == k % h->world) r2 = dp_checksum(h, h->att[k].stream, ptrs[k], counts[k], rootv + 2 * k);
+                if (r2 == SRK_OK) r2 = dp_allreduce_host(h, rootv, 2 * G);
+            }
             if (r2 == SRK_OK) r2 = coll_group(h, SRK_COLL_BCAST, G, ptrs, counts);
+            if (verify) {
+                if (r2 == SRK_E_DEVICE) return selfcheck_failed("an RCCL call of the broadcast group returned an error");
+                bad = 0;
+                for (int k = 0; k < G && r2 == SRK_OK; ++k) {
+                    double got[2];
+                    r2 = dp_checksum(h, h->att[k].stream, ptrs[k], counts[k], got);
+                    // (a broadcast copies bits and the checksum has a fixed order: equal, not close; NaN corrections of a failed
+                    // solve compare unequal to themselves and are let through -- the status words deal with them)
+                    if (got[0] == got[0] && rootv[2 * k] == rootv[2 * k] && (got[0] != rootv[2 * k] || got[1] != rootv[2 * k + 1])) bad += 1;
+                }
+#ifdef SRK_DEV
+                if (g_dp_corrupt == 2) bad += 1, g_dp_corrupt = 0;
+#endif
+                if (r2 == SRK_OK) r2 = dp_allreduce_host(h, &bad, 1);
+                if (r2 == SRK_OK && bad > 0) return selfcheck_failed("broadcast corrections differ from the solving rank's");
+                if (r2 == SRK_OK) h->dp_verified = true;
+            }
             for (int k = 0; k < G && r2 == SRK_OK; ++k) {
                 select_attempt(h, k);
                 r2 = phase_backsub_apply(h, cf[k]);
@@ -2180,6 +2274,14 @@ int srk_ba_optimize(srk_ba* h, const double* allowed_err_change, const double* m
                 cf[G++] = cc;
             }
             rc = dp_round(G, cf);
+            if (rc == SRK_RETRY_ALLREDUCE) { // the first native round failed its self-check (every rank saw the same verdict):
+                // nothing of it was judged; the systems are rebuilt and this iteration's attempts run through the all-reduce schedule
+                dp_mode = false;
+                h->poisoned = true;
+                rc = clear_poison(h);
+                if (rc != SRK_OK) return fail_device(rc);
+                break;
+            }
             if (rc != SRK_OK) return fail_device(rc);
             bool timeout = false;
             for (int k = 0; k < G; ++k) timeout = timeout || (((int)h->att[k].host_back[1] & 8) != 0);
@@ -2914,6 +3016,21 @@ int64_t srk_ba_iteration_log(srk_ba* h, int64_t cap, int32_t* attempts, double* 
 }
 int srk_ba_solver_fusion(srk_ba* h) { return h ? (h->chol_fused ? 1 : 0) : -1; }
 
+int srk_ba_set_multi_schedule(srk_ba* h, int mode)
+{
+    if (!h || mode < 0 || mode > 2) return SRK_E_ARGS;
+    h->dp_schedule = mode != 0;
+    h->dp_force = mode == 2;
+    h->dp_selfcheck_failed = false;
+    return SRK_OK;
+}
+int srk_ba_multi_schedule(srk_ba* h)
+{
+    if (!h) return -1;
+    if (h->dp_selfcheck_failed) return 3;
+    if (!h->dp_schedule) return 0;
+    return h->dp_verified ? 2 : 1;
+}
 int srk_ba_set_speculation(srk_ba* h, int on)
 {
     if (!h || (on != 0 && on != 1)) return SRK_E_ARGS;

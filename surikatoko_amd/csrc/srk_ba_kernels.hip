@@ -2178,8 +2178,12 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
     if (n_groups <= 0) return;
     // runs over at most SRK_WS_NF frames go to the MFMA kernel, fp64 only (the opt-in fp32 accumulation keeps the packed
     // FMA register-tile kernel).  SRK_SCHUR_NO_WS / SRK_SCHUR_VALU: development switches back to the register-tile kernels.
+#ifdef SRK_DEV
     static const bool env_no_ws = getenv("SRK_SCHUR_NO_WS") != nullptr;
     static const bool env_valu = getenv("SRK_SCHUR_VALU") != nullptr; // development: the register-tile kernel k_schur_ws
+#else
+    const bool env_no_ws = false, env_valu = false;
+#endif
     const bool no_ws = env_no_ws || fp32_accumulate;
     const int nf_skip = no_ws ? 0 : SRK_WS_NF;
 #define SRK_SCHUR_ARGS(WP) d, c, row_ptr, obs_pt, obs_slot, pt_mask, WP, Vg, S, rhs, grp_first, grp_count, grp_nf, grp_frames
@@ -2697,6 +2701,43 @@ void srk_launch_band_pack(hipStream_t s, int64_t ld, const int64_t* band_col, co
                           double* packed, int dir)
 {
     hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((ld + 3) / 4)), dim3(256), 0, s, ld, band_col, band_off, S, packed, dir);
+}
+
+// checksum of a buffer, {sum, sum of magnitudes}, in a fixed order (256 contiguous pieces, a fixed tree inside each, a fixed
+// tree over the pieces): the self-check of the first damping-parallel round (srk_ba_host.hip: dp_selfcheck)
+__global__ __launch_bounds__(256) void k_checksum_part(const double* __restrict__ p, int64_t n, double* __restrict__ part)
+{
+    __shared__ double ss[256], sa[256];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    double s = 0, a = 0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double v = p[i];
+        s += v;
+        a += fabs(v);
+    }
+    ss[threadIdx.x] = s, sa[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) ss[threadIdx.x] += ss[threadIdx.x + w], sa[threadIdx.x] += sa[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[2 * blockIdx.x] = ss[0], part[2 * blockIdx.x + 1] = sa[0];
+}
+__global__ __launch_bounds__(256) void k_checksum_final(const double* __restrict__ part, double* __restrict__ out2)
+{
+    __shared__ double ss[256], sa[256];
+    ss[threadIdx.x] = part[2 * threadIdx.x], sa[threadIdx.x] = part[2 * threadIdx.x + 1];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) ss[threadIdx.x] += ss[threadIdx.x + w], sa[threadIdx.x] += sa[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out2[0] = ss[0], out2[1] = sa[0];
+}
+void srk_launch_checksum(hipStream_t s, const double* p, int64_t n, double* part /* 512 doubles of scratch */, double* out2)
+{
+    hipLaunchKernelGGL(k_checksum_part, dim3(256), dim3(256), 0, s, p, n, part);
+    hipLaunchKernelGGL(k_checksum_final, dim3(1), dim3(256), 0, s, part, out2);
 }
 
 // ------------------------------------------------------------------ multi-view-factorization steps

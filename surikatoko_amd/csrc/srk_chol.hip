@@ -718,8 +718,11 @@ __device__ __forceinline__ void st_load_tile512(double (*sD)[LDSP], const double
 // test hook (srk_dbg_step_fault): the next N launches' diagonal-block workgroup of item 0 stops after its first tile and
 // publishes nothing -- every consumer of that item runs into its spin bound, bit 8 of *info is set and the host repeats
 // the solve unfused
+// -- in the development build only (make dev: libsrk_ba_dev.so, -DSRK_DEV; tests/_dev_worker.py loads it in a subprocess)
+#ifdef SRK_DEV
 __device__ int g_step_fault = 0;
 extern "C" void srk_dbg_step_fault(int launches) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_fault), &launches, sizeof(int)); }
+#endif
 #ifdef SRK_STEP_STAMPS // development (tools/step_stamps.sh): wall-clock stamps of item 0's workgroups of one launch
 __device__ long long g_step_stamps[8][32];
 #define SST(k) do { if (blockIdx.z == 0 && K == 0 && (threadIdx.x & 255) == 0 && blockIdx.x < 4) g_step_stamps[2 * blockIdx.x + (threadIdx.x >> 8)][k] = wall_clock64(); } while (0)
@@ -1083,10 +1086,12 @@ __global__ __launch_bounds__(STP_THREADS) void k_step256(const CholBatch B, cons
             if (tid < 7) sCnt[tid] = 0;
             if (tid == 7) { // (test hook, see diag_fault)
                 int f = 0;
+#ifdef SRK_DEV
                 if (z == 0) {
                     f = g_step_fault;
                     if (f > 0) atomicSub(&g_step_fault, 1);
                 }
+#endif
                 sCnt[7] = f > 0 ? 1u : 0u;
             }
             const int r = tid >> 3, cb = (tid & 7) * 8;

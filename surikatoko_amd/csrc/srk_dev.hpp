@@ -131,6 +131,8 @@ void srk_launch_env_pack(hipStream_t s, int64_t ld, const int64_t* env_col, cons
 void srk_launch_band_pack(hipStream_t s, int64_t ld, const int64_t* band_col, const int64_t* band_off, double* S,
                           double* packed, int dir /* 0 pack, 1 unpack */);
 
+void srk_launch_checksum(hipStream_t s, const double* p, int64_t n, double* part /* 512 doubles of scratch */, double* out2 /* {sum, sum |.|} */);
+
 // ---- multi-view-factorization steps (srk_ba_kernels.hip) ----
 void srk_launch_mvf_depth(hipStream_t s, int64_t n_tracks, const int64_t* row_ptr, const int32_t* frame, const double* x_meter,
                           const double* cam_R, const double* cam_T, double* depth);

@@ -33,6 +33,9 @@ CONFIGS = {
     # 36 cams, 4983 pts; config_scene() trims the 4-frame windows to the 16432 observations the dino flagfile states
     "C1_dino_standin": SceneSpec(36, 33, 151, vis_window=4),
     "C2_200cam_20kpt": SceneSpec(200, 200, 100, vis_window=20),      # 400k obs
+    # config 2 the way the reference's demo itself builds it (demo-bundle-adj-circle-grid.cpp:196-207: every point projected
+    # into every frame): 4M obs, a DENSE 1993^2 reduced camera system ("one run with full visibility")
+    "C2_all_visible": SceneSpec(200, 200, 100, vis_window=0),
     "C3_1kcam_100kpt": SceneSpec(1000, 400, 250, vis_window=20),     # 2M obs (headline)
     "C5_4kcam_1Mpt": SceneSpec(4000, 1000, 1000, vis_window=20),     # 20M obs
     "demo_circle_grid": SceneSpec(36, 5, 5, vis_window=0),           # the demo's own 36-frame all-visible scene

@@ -11,7 +11,6 @@ if ROOT not in sys.path:
 
 
 def run(rank, world, port, out_dir, spec_kwargs, iters, schedule="dp"):
-    os.environ["SRK_MULTI_SCHEDULE"] = schedule  # read by srk_ba_create: "dp" (default) or "allreduce"
     os.environ["SRK_DEBUG"] = "1"  # per-attempt trace on stderr: shows up in the pytest log when an assertion fails
     import torch.distributed as dist
     import surikatoko_amd as sa
@@ -23,6 +22,7 @@ def run(rank, world, port, out_dir, spec_kwargs, iters, schedule="dp"):
                             init_method="file://" + os.path.join(out_dir, "rendezvous"))
     try:
         spec_kwargs = dict(spec_kwargs)
+        spec_kwargs.pop("_iters", None)
         shuffle = spec_kwargs.pop("_shuffle", None)
         drop = spec_kwargs.pop("_drop", None)
         spec = sa.SceneSpec(**spec_kwargs)
@@ -35,6 +35,7 @@ def run(rank, world, port, out_dir, spec_kwargs, iters, schedule="dp"):
         assert ok
         shard, (lo, hi) = full.shard(rank, world)
         ba = sa.BundleAdjustmentKanatani(0)
+        ba.set_multi_schedule(schedule)  # "dp" (default) or "allreduce"; before the upload (it sizes the attempt slots)
         hook = make_allreduce_hook(None, "cuda:0")
         ba.set_allreduce(hook, rank, world)
         # the numbering is found on the WHOLE scene and given to every rank (a shard's own would differ from rank to rank)

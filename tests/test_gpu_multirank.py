@@ -29,12 +29,16 @@ def _free_port():
 # BASELINE config 4 = the headline scene (1000 cams / 100 000 pts / 2 000 000 obs) with its landmarks sharded: the same
 # workload, shard sizes per rank of a 2- and a 4-GPU run, through Scene.shard + band exchange + nested plan
 C3 = dict(n_frames=1000, grid_nx=400, grid_ny=250, vis_window=20)
+# BASELINE config 5 (4000 cams / 1M pts / 20M obs, the HBM-bound stress configuration of the 8-GPU line) through the sharded
+# path: shard sizes of a 2- and a 4-GPU run, 32-chunk plan, 400 MB band per damping factor, three reduced camera systems of
+# 12.8 GB per rank (all ranks on ONE GPU here: 4 x 3 x 12.8 GB of systems alone); two iterations
+C5 = dict(n_frames=4000, grid_nx=1000, grid_ny=1000, vis_window=20, _iters=2)
 
 
 # schedule "dp" (default at world >= 2): damping-parallel -- every rank builds the round's two or three damping factors on its
 # shard, band k is reduced to rank k, rank k solves and broadcasts its corrections, all ranks score every factor;
 # "allreduce": the round-2 schedule (band all-reduced, every rank solves redundantly, speculative pairs)
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1100)
 @pytest.mark.parametrize("world,spec_kwargs,min_chunks,schedule", [
     (2, dict(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7), 0, "dp"),                       # single skyline chain
     (2, dict(n_frames=30, grid_nx=23, grid_ny=17, vis_window=7), 0, "allreduce"),
@@ -42,17 +46,19 @@ C3 = dict(n_frames=1000, grid_nx=400, grid_ny=250, vis_window=20)
     (3, dict(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2), 2, "allreduce"),
     (2, C3, 8, "dp"),
     (4, C3, 8, "dp"),
+    (2, C5, 16, "dp"),
+    (4, C5, 16, "dp"),
     # frame numbers shuffled: every rank is given the numbering found on the whole scene (srk_ba_set_frame_order)
     (2, dict(n_frames=400, grid_nx=60, grid_ny=40, vis_window=10, noise_uv_pix=0.2, _shuffle=3), 2, "dp"),
     # ragged tracks (20 % of the observations dropped): the shards' runs are unions of frame lists (masked Schur / derivative kernels)
     (3, dict(n_frames=400, grid_nx=80, grid_ny=50, vis_window=16, noise_uv_pix=0.2, _drop=0.2), 2, "dp"),
 ], ids=["w2_30cam", "w2_30cam_allreduce", "w3_400cam", "w3_400cam_allreduce", "w2_C3_1kcam_100kpt", "w4_C3_1kcam_100kpt",
-        "w2_400cam_frames_shuffled", "w3_400cam_ragged"])
+        "w2_C5_4kcam_1Mpt", "w4_C5_4kcam_1Mpt", "w2_400cam_frames_shuffled", "w3_400cam_ragged"])
 def test_sharded_run_matches_single_process(tmp_path, world, spec_kwargs, min_chunks, schedule):
     import torch.multiprocessing as mp
     import _dist_gpu_worker
-    iters = 3  # far from convergence: no accept / reject decision is a near tie that summation order could flip
     kw = dict(spec_kwargs)
+    iters = kw.pop("_iters", 3)  # far from convergence: no accept / reject decision is a near tie that summation order could flip
     shuffle = kw.pop("_shuffle", None)
     drop = kw.pop("_drop", None)
     spec = sa.SceneSpec(**kw)
