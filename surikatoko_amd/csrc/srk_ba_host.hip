@@ -828,6 +828,8 @@ static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr
     const size_t wpr = ((size_t)M + 63) / 64;
     std::vector<uint64_t> adj((size_t)M * wpr, 0);
     std::unordered_set<uint64_t> seen;
+    int64_t pair_work = 0;
+    const int64_t pair_budget = 400000000; // ~1 s of host time
     for (int64_t i = 0; i < N; ++i) {
         const int64_t k = row_ptr[i + 1] - row_ptr[i];
         if (k < 2) continue;
@@ -835,11 +837,21 @@ static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr
         uint64_t hsh = 1469598103934665603ull ^ (uint64_t)k;
         for (int64_t a = 0; a < k; ++a) hsh = (hsh ^ (uint64_t)(uint32_t)f[a]) * 1099511628211ull;
         if (!seen.insert(hsh).second) continue; // (a collision only costs ordering quality: the skyline is built from the observations)
-        for (int64_t a = 0; a < k; ++a)
-            for (int64_t b = a + 1; b < k; ++b) {
-                adj[(size_t)f[a] * wpr + (size_t)(f[b] >> 6)] |= 1ull << (f[b] & 63);
-                adj[(size_t)f[b] * wpr + (size_t)(f[a] >> 6)] |= 1ull << (f[a] & 63);
-            }
+        auto link = [&](int32_t u, int32_t v) {
+            adj[(size_t)u * wpr + (size_t)(v >> 6)] |= 1ull << (v & 63);
+            adj[(size_t)v * wpr + (size_t)(u >> 6)] |= 1ull << (u & 63);
+        };
+        // all pairs of a list while the work stays bounded (long ragged tracks in an unordered set: ~1e6 distinct lists of
+        // ~500 frames would be 1e11 insertions before the first kernel); beyond the budget a list's chain of consecutive
+        // frames plus its first-last pair, which keeps the graph connected along every track
+        if (pair_work + k * (k - 1) / 2 <= pair_budget) {
+            pair_work += k * (k - 1) / 2;
+            for (int64_t a = 0; a < k; ++a)
+                for (int64_t b = a + 1; b < k; ++b) link(f[a], f[b]);
+        } else {
+            for (int64_t a = 0; a + 1 < k; ++a) link(f[a], f[a + 1]);
+            link(f[0], f[k - 1]);
+        }
     }
     std::vector<int32_t> deg((size_t)M, 0);
     for (int32_t j = 0; j < M; ++j)
@@ -848,10 +860,24 @@ static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr
     std::vector<char> done((size_t)M, 0);
     // breadth-first levels of the component of `root` among the frames not yet numbered; returns the last level's
     // frame of smallest degree and the depth
+    std::vector<int32_t> stamp((size_t)M, 0); // visited in THIS search: stamp == bfs_id (no copy of an M-byte array per search)
+    int32_t bfs_id = 0;
     auto bfs = [&](int32_t root, std::vector<int32_t>& out, int32_t& depth) -> int32_t {
         out.clear();
         out.push_back(root);
-        std::vector<char> vis(done);
+        ++bfs_id;
+        struct Vis {
+            const std::vector<char>& done;
+            std::vector<int32_t>& stamp;
+            int32_t id;
+            struct Ref {
+                Vis& v;
+                size_t i;
+                operator bool() const { return v.done[i] || v.stamp[i] == v.id; }
+                Ref& operator=(int) { v.stamp[i] = v.id; return *this; }
+            };
+            Ref operator[](size_t i) { return Ref{ *this, i }; }
+        } vis{ done, stamp, bfs_id };
         vis[(size_t)root] = 1;
         level[(size_t)root] = 0;
         for (size_t q = 0; q < out.size(); ++q) {
@@ -908,10 +934,33 @@ static bool frame_reorder(int mode, int64_t N, int32_t M, const int64_t* row_ptr
 }
 
 static void rearm_fusion(srk_ba* h);
+static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
+                             const double* cam_R_in, const double* cam_T_in, const double* K_in, int shared_k,
+                             const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                             int already_normalized);
+// (the upload allocates host vectors and starts sorting threads: nothing of that may leave through the C ABI as an exception)
 extern "C" int srk_ba_upload_scene(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
                                    const double* cam_R_in, const double* cam_T_in, const double* K_in, int shared_k,
                                    const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
                                    int already_normalized)
+{
+    try {
+        return upload_scene_impl(h, f0, N, pts_in, M, cam_R_in, cam_T_in, K_in, shared_k, row_ptr, obs_frame, obs_uv, already_normalized);
+    } catch (const std::bad_alloc&) {
+        if (h) h->last_error = "upload: out of host memory", h->have_scene = false;
+        return SRK_E_NOMEM;
+    } catch (const std::exception& e) {
+        if (h) h->last_error = std::string("upload: ") + e.what(), h->have_scene = false;
+        return SRK_E_DEVICE;
+    } catch (...) {
+        if (h) h->last_error = "upload: unknown exception", h->have_scene = false;
+        return SRK_E_DEVICE;
+    }
+}
+static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_in, int32_t M,
+                             const double* cam_R_in, const double* cam_T_in, const double* K_in, int shared_k,
+                             const int64_t* row_ptr, const int32_t* obs_frame, const double* obs_uv,
+                             int already_normalized)
 {
     auto t_stage = std::chrono::steady_clock::now();
     auto stage = [&](const char* what) { // SRK_DEBUG=1: where the host time of an upload goes
