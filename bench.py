@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--sequential-attempts", action="store_true",
                     help="one attempt slot (srk_ba_set_speculation off): kernels of different attempts never overlap, "
                          "so per-kernel durations under rocprofv3 are those of the kernel alone (profiles/)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="srk_ba_set_deterministic: ordered sums instead of fp64 atomics (never the default line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-call", action="store_true", help="skip the one-call (upload + LM + download) latency probe")
     ap.add_argument("--cpu-sample", default="C2_200cam_20kpt")
@@ -299,6 +301,8 @@ def main():
         ba.set_storage_precision(True)
     if args.sequential_attempts:
         ba.set_speculation(False)
+    if args.deterministic:
+        ba.set_deterministic(True)
     exchange = "none"
     if world > 1:
         # N > 1: the library's own RCCL all-reduces on its streams (srk_ba_rccl_init; the unique id travels through
@@ -353,6 +357,7 @@ def main():
     if args.rcs != "dense" and world > 1:
         from surikatoko_amd.ba import covisibility
         ba.set_covisibility(covisibility(scene))  # global skyline: every rank factorises the same all-reduced system
+    deterministic_on = ba.deterministic()
     rcs_fill = ba.rcs_fill()
     mfma_flops = ba.solve_mfma_flops()
     rcs_chunks = ba.rcs_chunks()
@@ -604,6 +609,7 @@ def main():
                        "lm_attempts": "one attempt at a time (--sequential-attempts)" if args.sequential_attempts else
                                       "two attempt slots: the next damping factor runs beside the current one and is "
                                       "judged in the reference's order (srk_ba_set_speculation)"},
+            "deterministic_mode": bool(deterministic_on),
             "iterations_done": iterations,
             "attempts": int(attempts_timed),
             "attempts_by_iteration": att_log,
@@ -661,7 +667,7 @@ def main():
                           "step": "one accepted outer LM iteration with its rejected attempts, one continuing run",
                           "parallelism": out["config"]["parallelism"], "exchange": exchange, "rcs_solver": args.rcs,
                           "rcs_chunks": rcs_chunks,
-                          "schedule": schedule_used,
+                          "schedule": schedule_used, "deterministic": bool(deterministic_on),
                           "lm_attempts": ("sequential" if args.sequential_attempts and world == 1 else
                                           ("speculative pairs" if world == 1 or not schedule_used.startswith("dp") else
                                            f"{min(3, world)} damping factors a round, one per rank"))}

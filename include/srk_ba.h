@@ -275,6 +275,19 @@ int64_t srk_ba_iteration_log(srk_ba*, int64_t cap, int32_t* attempts, double* ms
  * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time. */
 int srk_ba_set_speculation(srk_ba*, int on);
 
+/* Deterministic mode (default off; takes effect at the next upload).  The reference is sequential: it adds every landmark's
+ * contribution in point order (bundle-adj-kanatani.cpp:1862-1898) and two runs give the same bits.  By default the derivative
+ * and the Schur kernels here combine partial sums with fp64 atomics, whose arrival order differs from run to run: results
+ * agree to rounding, and where two attempts' errors tie at that level the accept / reject sequence can fork.  With the mode
+ * on, a derivative task's frame sums and a run's Schur sum go to staging buffers and an ordered second pass adds them (per
+ * frame in task order, per block in run order): the same scene gives the same bits every time, at the cost of that pass
+ * (+ ~0.16 GB of staging per attempt slot at 1000 frames).  Covered: scenes whose tracks span at most 20 frames (the
+ * run-based derivative kernel and the MFMA Schur kernel; every BASELINE configuration), one rank, fp64 run sums.
+ * srk_ba_deterministic: 1 when the uploaded scene runs that way, 0 when the mode is off or the scene is not covered (the
+ * default kernels then run). */
+int srk_ba_set_deterministic(srk_ba*, int on);
+int srk_ba_deterministic(srk_ba*);
+
 /* Exchange schedule of the LM loop with several ranks (landmark shards; takes effect at the next upload):
  *   1 (default) damping-parallel: a round builds the next min(3, world) damping factors c, 10c, 100c on every shard, band k is
  *     REDUCED to rank k, rank k solves factor k and broadcasts its corrections, every rank scores all of them and one

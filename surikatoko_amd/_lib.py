@@ -55,7 +55,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 EXPORTS = [
     "srk_ba_create", "srk_ba_destroy", "srk_ba_last_error", "srk_ba_status_string", "srk_ba_device_count",
     "srk_ba_set_stream", "srk_ba_set_allreduce", "srk_ba_rccl_get_unique_id", "srk_ba_rccl_init", "srk_ba_rccl_init_second", "srk_ba_rccl_set_comm", "srk_ba_compute_inplace", "srk_ba_compute_inplace_f32", "srk_ba_reproj_error", "srk_ba_reproj_error_mvf", "srk_mvf_estimate_depths", "srk_mvf_relative_motion",
-    "srk_mvf_project_onto_so3", "srk_ba_set_schur_precision", "srk_ba_set_storage_precision", "srk_ba_set_speculation", "srk_ba_set_multi_schedule", "srk_ba_multi_schedule", "srk_ba_set_frame_reordering", "srk_ba_set_frame_order", "srk_ba_frame_order", "srk_frame_order", "srk_ba_set_solver_fusion", "srk_ba_solver_sync_timeouts", "srk_ba_iteration_log", "srk_ba_solver_fusion", "srk_ba_set_jacobian_mode", "srk_ba_jacobian_kernel",
+    "srk_mvf_project_onto_so3", "srk_ba_set_schur_precision", "srk_ba_set_storage_precision", "srk_ba_set_speculation", "srk_ba_set_deterministic", "srk_ba_deterministic", "srk_ba_set_multi_schedule", "srk_ba_multi_schedule", "srk_ba_set_frame_reordering", "srk_ba_set_frame_order", "srk_ba_frame_order", "srk_frame_order", "srk_ba_set_solver_fusion", "srk_ba_solver_sync_timeouts", "srk_ba_iteration_log", "srk_ba_solver_fusion", "srk_ba_set_jacobian_mode", "srk_ba_jacobian_kernel",
     "srk_ba_normalize_scene", "srk_ba_revert_normalization", "srk_ba_check_world_is_normalized",
     "srk_ba_upload_scene", "srk_ba_optimize", "srk_ba_download_scene", "srk_ba_reset_scene", "srk_ba_phase_error",
     "srk_ba_phase_derivatives", "srk_ba_phase_schur", "srk_ba_phase_solve", "srk_ba_phase_backsub",

@@ -293,6 +293,14 @@ class BundleAdjustmentKanatani:
         """Run the next damping factor beside the current attempt (one rank, instrumentation off); next upload."""
         self._raise(self._lib.srk_ba_set_speculation(C.c_void_p(self._h), C.c_int(int(bool(on)))))
 
+    def set_deterministic(self, on=True):
+        """ordered sums instead of fp64 atomics (srk_ba_set_deterministic); takes effect at the next upload"""
+        self._raise(self._lib.srk_ba_set_deterministic(C.c_void_p(self._h), C.c_int(int(bool(on)))))
+
+    def deterministic(self):
+        """True when the uploaded scene runs in deterministic mode (srk_ba_deterministic)"""
+        return int(self._lib.srk_ba_deterministic(C.c_void_p(self._h))) == 1
+
     MULTI_SCHEDULES = {"allreduce": 0, "dp": 1, "dp_force": 2}
 
     def set_multi_schedule(self, schedule="dp"):

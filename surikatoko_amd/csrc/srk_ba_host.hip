@@ -76,6 +76,12 @@ struct srk_ba {
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // run-based Jacobian kernel (k_jac_runs): tasks = pieces of runs of landmarks with identical frame lists
     DevBuf jr_first, jr_count, jr_jmin, jr_group;
+    // deterministic mode (srk_ba_set_deterministic; srk_dev.hpp: SrkDetJac / SrkDetSchur): index tables of the ordered second
+    // passes and the derivative kernel's staging buffer (the Schur kernel's are per attempt slot)
+    bool deterministic = false;       // asked for (takes effect at the next upload)
+    bool det_active = false;          // the uploaded scene runs that way (every landmark through k_jac_runs / k_schur_mm)
+    DevBuf dj_ptr, dj_ent, dj_stage, ds_pair_ptr, ds_pair_fa, ds_pair_fb, ds_pair_ent, ds_f_ptr, ds_f_ent;
+    int32_t ds_n_pairs = 0;
     bool jac_runs_masked = false; // the tasks are pieces of the Schur kernel's runs over UNIONS of frame lists (ragged tracks)
     int32_t jr_tasks = 0, jr_min_nf = 64;
     bool jac_runs = false;  // the tasks are long enough to pay and every workgroup's frame window fits
@@ -94,6 +100,7 @@ struct srk_ba {
     struct Attempt {
         DevBuf S, rhs, wy, dc, acc, dx, err_partial, info, dinv, packed, sync_flags;
         DevBuf irr; // [0] count + landmarks the SYRK form of k_schur_mm hands back to the per-landmark inverse path
+        DevBuf det_stage, det_rhs; // deterministic mode: the runs' staged sums (SrkDetSchur)
         SrkChunkPlan plan;
         SrkCholSync sync;            // in-launch hand-offs of the fused outer-step kernel (srk_chol.hip: k_step256)
         std::vector<DevBuf> plan_bufs;
@@ -340,11 +347,12 @@ void srk_ba_destroy(srk_ba* h)
                       &h->obs_frame, &h->obs_pt, &h->obs_uv, &h->col_ptr, &h->fobs_pt, &h->fobs_uv, &h->W, &h->Vg, &h->Ug,
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
                       &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off,
+                      &h->dj_ptr, &h->dj_ent, &h->dj_stage, &h->ds_pair_ptr, &h->ds_pair_fa, &h->ds_pair_fb, &h->ds_pair_ent, &h->ds_f_ptr, &h->ds_f_ent,
                       &h->jr_first, &h->jr_count, &h->jr_jmin, &h->jr_group, &h->lg_item, &h->lg_np, &h->lg_nf, &h->lg_pts, &h->lg_frames,
                       &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
     for (auto& a : h->att) {
-        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr }) dev_free(*b);
+        for (DevBuf* b : { &a.S, &a.rhs, &a.wy, &a.dc, &a.acc, &a.dx, &a.err_partial, &a.info, &a.dinv, &a.packed, &a.sync_flags, &a.irr, &a.det_stage, &a.det_rhs }) dev_free(*b);
         for (DevBuf& b : a.plan_bufs) dev_free(b);
         if (a.host_back) hipHostFree(a.host_back);
         if (a.done) hipEventDestroy(a.done);
@@ -1388,6 +1396,80 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
     }
     h->jr_tasks = h->jac_runs ? (int32_t)jr_first.size() : 0;
 
+    // ---- deterministic mode: tables of the ordered second passes.  Covered: scenes whose landmarks all take the run-based
+    // derivative kernel and the MFMA Schur kernel (tracks over at most SRK_WS_NF_HOST frames, fp64 run sums).
+    std::vector<int32_t> dj_ptr, dj_ent, ds_pair_ptr, ds_pair_fa, ds_pair_fb, ds_pair_ent, ds_f_ptr, ds_f_ent;
+    h->det_active = false;
+    if (h->deterministic && h->jac_runs && n_wide == 0 && n_mid == 0 && lg_item.empty() && gen_list.empty() && !h->schur_fp32 &&
+        !grp_first.empty() && grp_first.size() < ((size_t)1 << 20) && jr_first.size() < ((size_t)1 << 25)) {
+        bool all_mm = true;
+        for (int32_t v : grp_nf) all_mm = all_mm && std::abs(v) <= SRK_WS_NF_HOST;
+        if (all_mm) {
+            // derivative tasks by frame
+            dj_ptr.assign((size_t)M + 1, 0);
+            auto task_frames = [&](size_t t, const int32_t*& fr) -> int {
+                if (!jr_group.empty()) {
+                    const size_t gi = (size_t)jr_group[t];
+                    fr = grp_frames.data() + gi * SRK_GRP_MAXNF_HOST;
+                    return std::abs(grp_nf[gi]);
+                }
+                fr = of.data() + rp[(size_t)jr_first[t]];
+                return (int)(rp[(size_t)jr_first[t] + 1] - rp[(size_t)jr_first[t]]);
+            };
+            for (size_t t = 0; t < jr_first.size(); ++t) {
+                const int32_t* fr;
+                const int nf = task_frames(t, fr);
+                for (int f = 0; f < nf; ++f) ++dj_ptr[(size_t)fr[f] + 1];
+            }
+            for (int32_t j = 0; j < M; ++j) dj_ptr[(size_t)j + 1] += dj_ptr[(size_t)j];
+            dj_ent.resize((size_t)dj_ptr[(size_t)M]);
+            {
+                std::vector<int32_t> fill(dj_ptr.begin(), dj_ptr.end() - 1);
+                for (size_t t = 0; t < jr_first.size(); ++t) {
+                    const int32_t* fr;
+                    const int nf = task_frames(t, fr);
+                    for (int f = 0; f < nf; ++f) dj_ent[(size_t)fill[(size_t)fr[f]]++] = (int32_t)(t * 64 + (size_t)f);
+                }
+            }
+            // Schur runs by block (fa >= fb) and by frame
+            std::vector<std::pair<int64_t, int32_t>> ents;
+            ds_f_ptr.assign((size_t)M + 1, 0);
+            for (size_t gi = 0; gi < grp_first.size(); ++gi) {
+                const int nf = std::abs(grp_nf[gi]);
+                const int32_t* fr = grp_frames.data() + gi * SRK_GRP_MAXNF_HOST;
+                for (int sa = 0; sa < nf; ++sa) {
+                    ++ds_f_ptr[(size_t)fr[sa] + 1];
+                    for (int sb = 0; sb <= sa; ++sb)
+                        ents.emplace_back((int64_t)fr[sa] * M + fr[sb], (int32_t)((uint32_t)gi | (uint32_t)sa << 20 | (uint32_t)sb << 25));
+                }
+            }
+            std::stable_sort(ents.begin(), ents.end(), [](const std::pair<int64_t, int32_t>& x, const std::pair<int64_t, int32_t>& y) { return x.first < y.first; });
+            ds_pair_ent.reserve(ents.size());
+            for (size_t e = 0; e < ents.size(); ++e) {
+                if (e == 0 || ents[e].first != ents[e - 1].first) {
+                    ds_pair_ptr.push_back((int32_t)e);
+                    ds_pair_fa.push_back((int32_t)(ents[e].first / M));
+                    ds_pair_fb.push_back((int32_t)(ents[e].first % M));
+                }
+                ds_pair_ent.push_back(ents[e].second);
+            }
+            ds_pair_ptr.push_back((int32_t)ents.size());
+            for (int32_t j = 0; j < M; ++j) ds_f_ptr[(size_t)j + 1] += ds_f_ptr[(size_t)j];
+            ds_f_ent.resize((size_t)ds_f_ptr[(size_t)M]);
+            {
+                std::vector<int32_t> fill(ds_f_ptr.begin(), ds_f_ptr.end() - 1);
+                for (size_t gi = 0; gi < grp_first.size(); ++gi) {
+                    const int nf = std::abs(grp_nf[gi]);
+                    const int32_t* fr = grp_frames.data() + gi * SRK_GRP_MAXNF_HOST;
+                    for (int sa = 0; sa < nf; ++sa) ds_f_ent[(size_t)fill[(size_t)fr[sa]]++] = (int32_t)((uint32_t)gi | (uint32_t)sa << 20);
+                }
+            }
+            h->ds_n_pairs = (int32_t)ds_pair_fa.size();
+            h->det_active = true;
+        }
+    }
+    stage("deterministic-mode tables");
+
     // the frame-major copy of the observations (ordered by frame, then landmark): only the two-kernel derivative path reads it
     const bool need_frame_major = !h->jac_runs && !h->jac_fused;
     std::vector<int32_t> fobs_pt(need_frame_major ? (size_t)O : 0);
@@ -1438,6 +1520,10 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
         srk_ba::Attempt& a = h->att[sl];
         a.allocated = sl < n_slots;
         if (!a.allocated) continue;
+        if (h->det_active) {
+            ALLOC(a.det_stage, 8 * (int64_t)SRK_DET_STRIDE * (int64_t)grp_first.size());
+            ALLOC(a.det_rhs, 8 * (int64_t)SRK_DET_LD * (int64_t)grp_first.size());
+        }
         ALLOC(a.S, 8 * d.ld * d.ld);
         ALLOC(a.rhs, 8 * d.ld);
         ALLOC(a.wy, 8 * 2 * d.ld);
@@ -1477,6 +1563,17 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
         ALLOC(h->jr_jmin, 4 * jr_jmin.size());
         if (h->jac_runs_masked) ALLOC(h->jr_group, 4 * jr_group.size());
     }
+    if (h->det_active) {
+        ALLOC(h->dj_ptr, 4 * dj_ptr.size());
+        ALLOC(h->dj_ent, 4 * std::max<size_t>(dj_ent.size(), 1));
+        ALLOC(h->dj_stage, 8 * (int64_t)SRK_UG * 64 * (int64_t)jr_first.size());
+        ALLOC(h->ds_pair_ptr, 4 * ds_pair_ptr.size());
+        ALLOC(h->ds_pair_fa, 4 * std::max<size_t>(ds_pair_fa.size(), 1));
+        ALLOC(h->ds_pair_fb, 4 * std::max<size_t>(ds_pair_fb.size(), 1));
+        ALLOC(h->ds_pair_ent, 4 * std::max<size_t>(ds_pair_ent.size(), 1));
+        ALLOC(h->ds_f_ptr, 4 * ds_f_ptr.size());
+        ALLOC(h->ds_f_ent, 4 * std::max<size_t>(ds_f_ent.size(), 1));
+    }
 #undef ALLOC
     hipStream_t s = h->stream;
     stage("device allocations");
@@ -1498,6 +1595,16 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
     H2D(h->col_ptr, col_ptr.data(), 8 * ((int64_t)M + 1));
     H2D(h->fobs_pt, fobs_pt.data(), 4 * fobs_pt.size());
     H2D(h->fobs_uv, fobs_uv.data(), 8 * fobs_uv.size());
+    if (h->det_active) {
+        H2D(h->dj_ptr, dj_ptr.data(), 4 * dj_ptr.size());
+        H2D(h->dj_ent, dj_ent.data(), 4 * dj_ent.size());
+        H2D(h->ds_pair_ptr, ds_pair_ptr.data(), 4 * ds_pair_ptr.size());
+        H2D(h->ds_pair_fa, ds_pair_fa.data(), 4 * ds_pair_fa.size());
+        H2D(h->ds_pair_fb, ds_pair_fb.data(), 4 * ds_pair_fb.size());
+        H2D(h->ds_pair_ent, ds_pair_ent.data(), 4 * ds_pair_ent.size());
+        H2D(h->ds_f_ptr, ds_f_ptr.data(), 4 * ds_f_ptr.size());
+        H2D(h->ds_f_ent, ds_f_ent.data(), 4 * ds_f_ent.size());
+    }
     H2D(h->grp_first, grp_first.data(), 4 * grp_first.size());
     H2D(h->grp_count, grp_count.data(), 4 * grp_count.size());
     H2D(h->grp_nf, grp_nf.data(), 4 * grp_nf.size());
@@ -1766,12 +1873,13 @@ static int phase_derivatives(srk_ba* h)
     HIPCHK(h, hipMemsetAsync(h->Vg.p, 0, 8 * 9 * d.Ns, s));
     HIPCHK(h, hipMemsetAsync(h->Ug.p, 0, 8 * SRK_UG * (int64_t)d.M, s));
     if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[12], s));
+    const SrkDetJac detj{ P<double>(h->dj_stage), P<int32_t>(h->dj_ptr), P<int32_t>(h->dj_ent) };
     if (h->jac_runs) {
         srk_launch_jac_runs(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame),
                             P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg), P<double>(h->Ug), P<int32_t>(h->jr_first),
                             P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin),
                             h->jac_runs_masked ? P<int32_t>(h->jr_group) : nullptr, P<int32_t>(h->grp_nf), P<int32_t>(h->grp_frames),
-                            P<uint32_t>(h->pt_mask));
+                            P<uint32_t>(h->pt_mask), h->det_active ? &detj : nullptr);
         if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
     } else if (h->jac_fused) {
         srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),
@@ -1819,11 +1927,13 @@ static int phase_schur(srk_ba* h, double c, bool local_only)
     const SrkDims& d = h->d;
     hipStream_t s = h->stream;
     srk_launch_env_zero(s, d.ld, P<int64_t>(h->env_col), P<double>(h->A->S), P<double>(h->A->rhs), P<int32_t>(h->A->irr)); // S band, rhs, hand-back counter
+    const SrkDetSchur dets{ P<double>(h->A->det_stage), P<double>(h->A->det_rhs), P<int32_t>(h->ds_pair_ptr), P<int32_t>(h->ds_pair_fa),
+                            P<int32_t>(h->ds_pair_fb), P<int32_t>(h->ds_pair_ent), h->ds_n_pairs, P<int32_t>(h->ds_f_ptr), P<int32_t>(h->ds_f_ent) };
     srk_launch_schur_grouped(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_pt), P<uint8_t>(h->obs_slot),
                              P<uint32_t>(h->pt_mask), P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S),
                              P<double>(h->A->rhs), P<int32_t>(h->grp_first), P<int32_t>(h->grp_count), P<int32_t>(h->grp_nf),
                              P<int32_t>(h->grp_frames), h->n_groups, h->n_groups_wide, h->n_groups_mid, h->schur_fp32 ? 1 : 0,
-                             P<int32_t>(h->A->irr), h->n_mm_uniform, h->n_mm_ragged);
+                             P<int32_t>(h->A->irr), h->n_mm_uniform, h->n_mm_ragged, h->det_active ? &dets : nullptr);
     srk_launch_schur_long(s, d, c, P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S), P<double>(h->A->rhs),
                           P<int32_t>(h->lg_item), h->n_long_items, P<int32_t>(h->lg_np), P<int32_t>(h->lg_nf), P<int32_t>(h->lg_pts),
                           P<int32_t>(h->lg_frames), P<int64_t>(h->lg_obs_off), P<int32_t>(h->lg_obs));
@@ -3065,6 +3175,13 @@ int64_t srk_ba_iteration_log(srk_ba* h, int64_t cap, int32_t* attempts, double* 
 }
 int srk_ba_solver_fusion(srk_ba* h) { return h ? (h->chol_fused ? 1 : 0) : -1; }
 
+int srk_ba_set_deterministic(srk_ba* h, int on)
+{
+    if (!h) return SRK_E_ARGS;
+    h->deterministic = on != 0;
+    return SRK_OK;
+}
+int srk_ba_deterministic(srk_ba* h) { return (h && h->have_scene && h->det_active) ? 1 : 0; }
 int srk_ba_set_multi_schedule(srk_ba* h, int mode)
 {
     if (!h || mode < 0 || mode > 2) return SRK_E_ARGS;

@@ -442,7 +442,7 @@ void srk_launch_jac_fused(hipStream_t s, const SrkDims& d, const double* pts, co
 // (landmark m of the step, frame slot f of the union): the cell's observation is the landmark's first one plus the number of
 // mask bits below the slot; a cell the landmark does not see computes nothing and adds zeros to the landmark's sums.  A lane
 // still stays on one frame for the whole task.  The landmarks' first observations and masks sit in a per-wave LDS table.
-template <typename WT, bool MASKED>
+template <typename WT, bool MASKED, bool DET = false>
 __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __restrict__ pts,
                                                      const double* __restrict__ cam,
                                                      const int64_t* __restrict__ row_ptr,
@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                                                      const int32_t* __restrict__ task_count, int32_t n_tasks,
                                                      const int32_t* __restrict__ wg_jmin,
                                                      const int32_t* __restrict__ task_group, const int32_t* __restrict__ grp_nf,
-                                                     const int32_t* __restrict__ grp_frames, const uint32_t* __restrict__ pt_mask)
+                                                     const int32_t* __restrict__ grp_frames, const uint32_t* __restrict__ pt_mask,
+                                                     double* __restrict__ det_stage /* DET: [task][64][SRK_UG] */)
 {
     __shared__ int32_t sTOff[MASKED ? 4 : 1][MASKED ? SRK_JR_TASK_PTS_MAX_HOST : 1];
     __shared__ uint32_t sTMask[MASKED ? 4 : 1][MASKED ? SRK_JR_TASK_PTS_MAX_HOST : 1];
@@ -623,7 +624,23 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
             }
             asm volatile("" ::: "memory");
         }
-        if (on) {
+        if (DET) {
+            // deterministic mode (srk_ba_set_deterministic): no atomics.  The g lanes of a frame (one per landmark of a step)
+            // are summed in lane order, the first one stores the task's 65 sums of that frame; k_jac_det_gather adds the
+            // tasks' sums per frame in task order.
+            for (int m2 = 1; m2 < g; ++m2) {
+#pragma unroll
+                for (int k = 0; k < SRK_UG; ++k) {
+                    const double o = __shfl(acc[k], f + m2 * nf, WAVE);
+                    if (m == 0) acc[k] += o; // (the other lanes keep their own sums: they are read in the steps behind)
+                }
+            }
+            if (on && m == 0) {
+                double* dst = det_stage + ((int64_t)task * WAVE + f) * SRK_UG;
+#pragma unroll
+                for (int k = 0; k < SRK_UG; ++k) dst[k] = acc[k];
+            }
+        } else if (on) {
             double* su = sU[js];
             sTouched[js] = 1;
 #pragma unroll
@@ -631,6 +648,7 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
         }
     }
     }
+    if (DET) return;
     __syncthreads();
     for (int t = threadIdx.x; t < SRK_JF_SLOTS * SRK_UG; t += 256) {
         int slot = t / SRK_UG, k = t - slot * SRK_UG;
@@ -638,22 +656,41 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
     }
 }
 
+// deterministic mode: frame j's block and gradient = the tasks' sums of that frame, added in task order
+__global__ __launch_bounds__(128) void k_jac_det_gather(int32_t M, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ent,
+                                                        const double* __restrict__ stage, double* __restrict__ Ug)
+{
+    const int j = blockIdx.x, k = threadIdx.x;
+    if (j >= M || k >= SRK_UG) return;
+    double sum = 0;
+    for (int e = ptr[j]; e < ptr[j + 1]; ++e) sum += stage[(int64_t)ent[e] * SRK_UG + k];
+    Ug[(int64_t)j * SRK_UG + k] = sum;
+}
+
 void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, const double* cam, const int64_t* row_ptr,
                          const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
                          const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
-                         const int32_t* task_group, const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask)
+                         const int32_t* task_group, const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask,
+                         const SrkDetJac* det)
 {
     if (n_tasks <= 0) return;
     const dim3 grid((unsigned)((n_tasks + 3) / 4));
-#define SRK_JR_ARGS(WP) d, pts, cam, row_ptr, obs_frame, obs_uv, WP, Vg, Ug, task_first, task_count, n_tasks, wg_jmin, task_group, grp_nf, grp_frames, pt_mask
-    if (task_group) { // tasks over unions of frame lists (ragged tracks)
-        if (d.w_f32) hipLaunchKernelGGL((k_jac_runs<float, true>), grid, dim3(256), 0, s, SRK_JR_ARGS(reinterpret_cast<float*>(W)));
-        else hipLaunchKernelGGL((k_jac_runs<double, true>), grid, dim3(256), 0, s, SRK_JR_ARGS(W));
-    } else {
-        if (d.w_f32) hipLaunchKernelGGL((k_jac_runs<float, false>), grid, dim3(256), 0, s, SRK_JR_ARGS(reinterpret_cast<float*>(W)));
-        else hipLaunchKernelGGL((k_jac_runs<double, false>), grid, dim3(256), 0, s, SRK_JR_ARGS(W));
-    }
+#define SRK_JR_ARGS(WP) d, pts, cam, row_ptr, obs_frame, obs_uv, WP, Vg, Ug, task_first, task_count, n_tasks, wg_jmin, task_group, grp_nf, grp_frames, pt_mask, det ? det->stage : nullptr
+#define SRK_JR_LAUNCH(MASKED)                                                                                                         \
+    do {                                                                                                                              \
+        if (det) {                                                                                                                    \
+            if (d.w_f32) hipLaunchKernelGGL((k_jac_runs<float, MASKED, true>), grid, dim3(256), 0, s, SRK_JR_ARGS(reinterpret_cast<float*>(W))); \
+            else hipLaunchKernelGGL((k_jac_runs<double, MASKED, true>), grid, dim3(256), 0, s, SRK_JR_ARGS(W));                          \
+        } else {                                                                                                                      \
+            if (d.w_f32) hipLaunchKernelGGL((k_jac_runs<float, MASKED, false>), grid, dim3(256), 0, s, SRK_JR_ARGS(reinterpret_cast<float*>(W))); \
+            else hipLaunchKernelGGL((k_jac_runs<double, MASKED, false>), grid, dim3(256), 0, s, SRK_JR_ARGS(W));                         \
+        }                                                                                                                             \
+    } while (0)
+    if (task_group) SRK_JR_LAUNCH(true); // tasks over unions of frame lists (ragged tracks)
+    else SRK_JR_LAUNCH(false);
+#undef SRK_JR_LAUNCH
 #undef SRK_JR_ARGS
+    if (det) hipLaunchKernelGGL(k_jac_det_gather, dim3((unsigned)d.M), dim3(128), 0, s, d.M, det->ptr, det->ent, det->stage, Ug);
 }
 
 void srk_launch_jac_points(hipStream_t s, const SrkDims& d, const double* pts, const double* cam,
@@ -1643,13 +1680,15 @@ __device__ __forceinline__ void schur_mm_steps_row(srk_double4 (&acc)[SRK_MM_SLO
 // What was measured on the way (DESIGN sections 5 and 8): the helpers' instructions do not overlap with the MFMA streams of
 // their SIMD, so what counts is how FEW instructions both sides issue; latency hiding on the helper side, barrier-free
 // progress words, leaner block-wave address arithmetic each made it slower.
-template <typename WT, int KIND>
+template <typename WT, int KIND, bool DET = false>
 __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     SrkDims d, double c, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ obs_pt,
     const uint8_t* __restrict__ obs_slot, const uint32_t* __restrict__ pt_mask, const WT* __restrict__ W,
     const double* __restrict__ Vg, double* __restrict__ S, double* __restrict__ rhs,
     const int32_t* __restrict__ grp_first, const int32_t* __restrict__ grp_count, const int32_t* __restrict__ grp_nf,
-    const int32_t* __restrict__ grp_frames, int32_t* __restrict__ irr /* [0]: count, [1 ..]: landmarks handed back */)
+    const int32_t* __restrict__ grp_frames, int32_t* __restrict__ irr /* [0]: count, [1 ..]: landmarks handed back */,
+    double* __restrict__ det_stage /* DET: [run][SRK_DET_STRIDE], block (sa, sb) of the run's sum at (sa (sa + 1) / 2 + sb) 100 */,
+    double* __restrict__ det_rhs /* DET: [run][SRK_DET_LD] */)
 {
     constexpr int PB = SRK_GRP_PB;             // landmarks of a round
     constexpr int KR = 3 * PB;                 // k rows of a round
@@ -1777,8 +1816,10 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             const double hm = z_row(v, sE[rd * PB + pl], sm, z);
 #pragma unroll
             for (int i = 0; i < 5; ++i) wp[i] = make_double2(z[2 * i], z[2 * i + 1]);
+            if (!DET) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], z[i] * hm);
+                for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], z[i] * hm);
+            }
         } else if (masked && cell) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) wp[i] = make_double2(0.0, 0.0);
@@ -1786,6 +1827,14 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
     }
     const int nt = (nf10 + 15) >> 4; // tile rows of the sum
     __syncthreads(); // sE, sVar, sRhs and Z of rounds 0 and 1 are visible
+    if (DET && tid < nf10) {
+        // deterministic mode: the right-hand-side terms of rounds 0 and 1 from the staged Z rows, in row order (no LDS atomics)
+        double t0 = 0;
+        for (int rd = 0; rd < 2; ++rd)
+            for (int k = 0; k < KR; ++k)
+                if (rd * PB + k / 3 < np) t0 = fma(sBuf[rd * WB + k * LDW + tid], sE[rd * PB + k / 3][6 + k % 3], t0);
+        sRhs[tid] = t0;
+    }
     MM_STAMP(1);
     // two roles, two code paths, one barrier sequence (one, then one per double round, one at the end)
     if (wv >= SRK_MM_CW) {
@@ -1871,8 +1920,13 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
             MM_ACC(64 * SRK_MM_CW, 12, tacc);
         }
         if (sm < 3 && pl < PB) {
+            if (DET) { // every product is done (the loop's last barrier): the arena's first round buffer takes the lanes' sums
 #pragma unroll
-            for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], racc[i]);
+                for (int i = 0; i < 10; ++i) sBuf[dst + i] = racc[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) atomicAdd(&sRhs[10 * a + i], racc[i]);
+            }
         }
     } else {
         // ---- multipliers: wave wv owns up to eight tiles of the nt x nt grid
@@ -1965,8 +2019,10 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
         // it -- not once per entry: every vector-ALU instruction here is paid in MFMA time by the next workgroup's neighbours)
         int prev_ta = -1, rr4[4];
         int64_t rowoff[4];
+        int detrow[4], detva[4]; // DET: frame slot and variable of the lane's rows
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) { rr4[reg] = -1; rowoff[reg] = 0; }
+        for (int reg = 0; reg < 4; ++reg) { rr4[reg] = -1; rowoff[reg] = 0; detrow[reg] = detva[reg] = 0; }
+        double* const dstage = DET ? det_stage + (int64_t)blockIdx.x * SRK_DET_STRIDE : nullptr;
 #pragma unroll
         for (int s = 0; s < SRK_MM_SLOTS; ++s) {
             if (!((onmask >> s) & 1u)) continue;
@@ -1978,28 +2034,75 @@ __global__ __launch_bounds__(SRK_MM_THREADS) void k_schur_mm(
                     const int rowv = Rr < nf10 ? sVar[Rr] : -1;
                     rr4[reg] = rowv >= 0 ? Rr : -1; // -1: no such row, or a gauge-fixed variable
                     rowoff[reg] = (int64_t)rowv * d.ld;
+                    if (DET) detrow[reg] = Rr / 10, detva[reg] = Rr - 10 * (Rr / 10);
                 }
             }
             const int Cc = tb[s] + lr;
             const int colv = Cc < nf10 ? sVar[Cc] : -1;
             if (colv < 0) continue;
+            const int detsb = DET ? Cc / 10 : 0, detvb = DET ? Cc - 10 * (Cc / 10) : 0;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 if (Cc > rr4[reg]) continue; // above the diagonal, or no row
 #ifdef SRK_SCH_NOFLUSH
                 if (d.N >= 0) continue;
 #endif
-                atomicAdd(&S[rowoff[reg] + colv], -acc[s][reg]);
+                if (DET) // the run's sum goes to its own staging block; k_schur_det_gather adds the runs' blocks in run order
+                    dstage[(detrow[reg] * (detrow[reg] + 1) / 2 + detsb) * 100 + detva[reg] * 10 + detvb] = -acc[s][reg];
+                else atomicAdd(&S[rowoff[reg] + colv], -acc[s][reg]);
             }
         }
     }
     lds_barrier(); // the helpers' sRhs adds are complete
     // rhs += sum F^T E^-1 g
-    if (tid < nf10 && sVar[tid] >= 0) atomicAdd(&rhs[sVar[tid]], sRhs[tid]);
+    if (tid < nf10 && sVar[tid] >= 0) {
+        if (DET) {
+            double t1 = sRhs[tid];
+            for (int k = 0; k < KR; ++k) t1 += sBuf[k * LDW + tid];
+            det_rhs[(int64_t)blockIdx.x * SRK_DET_LD + tid] = t1;
+        } else atomicAdd(&rhs[sVar[tid]], sRhs[tid]);
+    }
     MM_STAMP(4);
 #ifdef SRK_MM_STAMPS
     if (tid == 0 && blockIdx.x < 2048) g_mm_stamps[blockIdx.x][9] = clock64() - g_mm_stamps[blockIdx.x][8];
 #endif
+}
+
+// deterministic mode, second pass: block (fa, fb) of the reduced camera system receives the runs' blocks in run order (ent:
+// run | slot of fa << 20 | slot of fb << 25), the right-hand side of frame f the runs' terms in run order (run | slot << 20)
+__global__ __launch_bounds__(128) void k_schur_det_gather(SrkDims d, const double* __restrict__ stage, const double* __restrict__ stage_rhs,
+                                                          const int32_t* __restrict__ pair_ptr, const int32_t* __restrict__ pair_fa,
+                                                          const int32_t* __restrict__ pair_fb, const int32_t* __restrict__ pair_ent,
+                                                          int32_t n_pairs, const int32_t* __restrict__ f_ptr, const int32_t* __restrict__ f_ent,
+                                                          double* __restrict__ S, double* __restrict__ rhs)
+{
+    const int e = threadIdx.x;
+    if ((int)blockIdx.x < n_pairs) {
+        const int p = blockIdx.x, fa = pair_fa[p], fb = pair_fb[p];
+        if (e >= 100) return;
+        const int va = e / 10, vb = e - 10 * va;
+        if (fa == fb && vb > va) return;
+        const int64_t row = 10 * (int64_t)fa + va, col = 10 * (int64_t)fb + vb;
+        if (srk_is_fixed_var(row, d) || srk_is_fixed_var(col, d)) return;
+        double sum = 0;
+        for (int k = pair_ptr[p]; k < pair_ptr[p + 1]; ++k) {
+            const unsigned u = (unsigned)pair_ent[k];
+            const int run = u & 0xFFFFF, sa = (u >> 20) & 31, sb = (u >> 25) & 31;
+            sum += stage[(int64_t)run * SRK_DET_STRIDE + (sa * (sa + 1) / 2 + sb) * 100 + e];
+        }
+        S[row * d.ld + col] += sum;
+    } else {
+        const int f = (int)blockIdx.x - n_pairs;
+        if (f >= d.M || e >= 10) return;
+        const int64_t row = 10 * (int64_t)f + e;
+        if (srk_is_fixed_var(row, d)) return;
+        double sum = 0;
+        for (int k = f_ptr[f]; k < f_ptr[f + 1]; ++k) {
+            const unsigned u = (unsigned)f_ent[k];
+            sum += stage_rhs[(int64_t)(u & 0xFFFFF) * SRK_DET_LD + 10 * (u >> 20) + e];
+        }
+        rhs[row] += sum;
+    }
 }
 
 // ------------------------------------------------------------------ K3l: long tracks as frame-block pairs (fp64 MFMA)
@@ -2173,7 +2276,7 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               const uint8_t* obs_slot, const uint32_t* pt_mask, const double* W, const double* Vg, double* S,
                               double* rhs, const int32_t* grp_first, const int32_t* grp_count, const int32_t* grp_nf,
                               const int32_t* grp_frames, int64_t n_groups, int64_t n_wide, int64_t n_mid,
-                              int fp32_accumulate, int32_t* irr, int64_t n_mm_uniform, int64_t n_mm_ragged)
+                              int fp32_accumulate, int32_t* irr, int64_t n_mm_uniform, int64_t n_mm_ragged, const SrkDetSchur* det)
 {
     if (n_groups <= 0) return;
     // runs over at most SRK_WS_NF frames go to the MFMA kernel, fp64 only (the opt-in fp32 accumulation keeps the packed
@@ -2205,12 +2308,20 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
         else {
 #define SRK_MM_LAUNCH(KIND)                                                                                                      \
     do {                                                                                                                         \
-        if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, KIND>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr);   \
-        else hipLaunchKernelGGL((k_schur_mm<double, KIND>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr);           \
+        if (det) {                                                                                                               \
+            if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, KIND, true>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr, det->stage, det->stage_rhs); \
+            else hipLaunchKernelGGL((k_schur_mm<double, KIND, true>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr, det->stage, det->stage_rhs);         \
+        } else {                                                                                                                 \
+            if (d.w_f32) hipLaunchKernelGGL((k_schur_mm<float, KIND, false>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(Wf), irr, nullptr, nullptr);          \
+            else hipLaunchKernelGGL((k_schur_mm<double, KIND, false>), grid, dim3(SRK_MM_THREADS), 0, s, SRK_SCHUR_ARGS(W), irr, nullptr, nullptr);                  \
+        }                                                                                                                        \
     } while (0)
             if (n_mm_ragged > 0) SRK_MM_LAUNCH(1);
             else if (n_mm_uniform > 0) SRK_MM_LAUNCH(0);
 #undef SRK_MM_LAUNCH
+            if (det && n_mm_ragged + n_mm_uniform > 0)
+                hipLaunchKernelGGL(k_schur_det_gather, dim3((unsigned)(det->n_pairs + d.M)), dim3(128), 0, s, d, det->stage, det->stage_rhs,
+                                   det->pair_ptr, det->pair_fa, det->pair_fb, det->pair_ent, det->n_pairs, det->f_ptr, det->f_ent, S, rhs);
         }
     }
     if (no_ws ? n_wide < n_groups : n_mid > 0) { // (SRK_WS_NF <) frames <= SRK_GRP_NF1: one half block per thread

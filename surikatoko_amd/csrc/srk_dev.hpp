@@ -45,6 +45,25 @@ struct SrkDims {
 
 #define SRK_CHOL_NB 256 // outer panel of the blocked Cholesky; ld is a multiple of it
 
+// ---- deterministic mode (srk_ba_set_deterministic): the sums that take fp64 atomics by default go through staging buffers and
+// an ordered second pass instead.  Derivative kernel: a task's 65 frame sums per frame slot, then per frame the tasks' sums in
+// task order.  Schur kernel: a run's sum as the 10 x 10 blocks (slot a >= slot b) of its lower block triangle and its
+// right-hand-side terms, then per block / per frame the runs' contributions in run order.
+#define SRK_DET_LD 200       // local variables of a run: SRK_WS_NF_HOST frames x 10
+#define SRK_DET_STRIDE 21000 // doubles of a run's staged sum: 20 * 21 / 2 blocks of 100
+struct SrkDetJac {
+    double* stage;            // [task][64][SRK_UG]
+    const int32_t* ptr;       // [M + 1]
+    const int32_t* ent;       // task * 64 + frame slot, by frame, tasks ascending
+};
+struct SrkDetSchur {
+    double* stage;            // [run][SRK_DET_STRIDE]
+    double* stage_rhs;        // [run][SRK_DET_LD]
+    const int32_t *pair_ptr, *pair_fa, *pair_fb, *pair_ent; // blocks (fa >= fb) that receive something; ent: run | slot a << 20 | slot b << 25
+    int32_t n_pairs;
+    const int32_t *f_ptr, *f_ent; // per frame: run | slot << 20
+};
+
 // ---- BA kernels (srk_ba_kernels.hip) ----
 void srk_launch_cam_pack(hipStream_t s, int32_t M, const double* R, const double* T, const double* K, double f0,
                          double* pack);
@@ -67,7 +86,8 @@ void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, con
                          const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
                          const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
                          const int32_t* task_group /* NULL: uniform runs; else the Schur run (grp_*) each task is a piece of */,
-                         const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask);
+                         const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask,
+                         const SrkDetJac* det = nullptr /* deterministic mode */);
 void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_obs, const double* pts,
                            const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
                            double* Ug);
@@ -88,7 +108,8 @@ void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const i
                               int64_t n_mid /* runs with SRK_WS_NF_HOST < frames <= SRK_GRP_NF1_HOST */,
                               int fp32_accumulate /* 0 = fp64 (reference arithmetic), 1 = packed fp32 run sums */,
                               int32_t* irr /* [0] count + list of landmarks k_schur_mm hands back to the inverse path */,
-                              int64_t n_mm_uniform, int64_t n_mm_ragged /* runs of <= SRK_WS_NF_HOST frames by kind */);
+                              int64_t n_mm_uniform, int64_t n_mm_ragged /* runs of <= SRK_WS_NF_HOST frames by kind */,
+                              const SrkDetSchur* det = nullptr /* deterministic mode (every run must be one of those) */);
 // tracks longer than SRK_GRP_MAXNF_HOST frames: runs of <= SRK_LONG_PTS_HOST landmarks over a frame set of
 // <= SRK_LONG_MAXNF_HOST frames, one workgroup per pair of 8-frame blocks (k_schur_long); longer tracks stay with k_schur.
 // (Round 3: 4096 -- the limit is only the row length of the run_frames table; it was 256, and a track over more frames fell
