@@ -84,6 +84,7 @@ struct srk_ba {
     int32_t ds_n_pairs = 0;
     bool jac_runs_masked = false; // the tasks are pieces of the Schur kernel's runs over UNIONS of frame lists (ragged tracks)
     int32_t jr_tasks = 0, jr_min_nf = 64;
+    int long_fb = SRK_LONG_FB_HOST; // frames per block of k_schur_long's pairs: 8, or 16 when the scene has enough of them
     bool jac_runs = false;  // the tasks are long enough to pay and every workgroup's frame window fits
     int jac_mode = -1;      // -1 = automatic, 0 = never k_jac_runs, 1 = whenever possible (srk_ba_set_jacobian_mode)
     // skyline of the reduced camera system (see k_env_zero): host + device copies
@@ -1218,19 +1219,42 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
                 uni.swap(merged);
                 ++cj;
             }
-            const int32_t run = (int32_t)lg_np.size();
-            const int nfu = (int)uni.size(), nb = (nfu + SRK_LONG_FB_HOST - 1) / SRK_LONG_FB_HOST, nfp = nb * SRK_LONG_FB_HOST;
+            const int nfu = (int)uni.size();
             lg_np.push_back((int32_t)(cj - ci));
             lg_nf.push_back((int32_t)nfu);
             for (int k = 0; k < SRK_LONG_PTS_HOST; ++k) lg_pts.push_back(ci + k < cj ? long_cand[ci + (size_t)k] : 0);
             for (int k = 0; k < SRK_LONG_MAXNF_HOST; ++k) lg_frames.push_back(k < nfu ? uni[(size_t)k] : -1);
+            ci = cj;
+        }
+    }
+    // Frame blocks of 8 or of 16 frames (round 4).  A workgroup stages both blocks of its pair for every landmark of the run:
+    // with 8-frame blocks that is two staged blocks for 25 MFMA tiles and the kernel spent its time staging (SQ counters on
+    // 200 frames x 20 000 points, every point in every frame: 7 vector-ALU, 0.85 memory and 0.9 LDS instructions per MFMA,
+    // matrix pipes 33 % busy); a pair of 16-frame blocks is two staged blocks for 100 tiles.  The larger blocks need enough
+    // pairs to fill the chip: small scenes (the 36- and 60-frame demo scenes) keep the 8-frame blocks.
+    {
+        int64_t items16 = 0, nf_sum = 0;
+        for (size_t r = 0; r < lg_np.size(); ++r) {
+            const int64_t nb16 = (lg_nf[r] + 15) / 16;
+            items16 += nb16 * (nb16 + 1) / 2;
+            nf_sum += lg_nf[r];
+        }
+        // (and frame sets long enough that the padding to 16 and the coarser diagonal pairs do not eat the gain.  Counting a
+        // staged block-frame as ~3 MFMA tiles -- what the counters above say -- 40 frames cost the same either way, 64 frames
+        // 30 % less with the larger blocks)
+        h->long_fb = (items16 >= 1024 && nf_sum >= 56 * (int64_t)lg_np.size()) ? 16 : SRK_LONG_FB_HOST;
+        const int FBh = h->long_fb;
+        for (size_t r = 0; r < lg_np.size(); ++r) {
+            const int32_t run = (int32_t)r;
+            const int nfu = lg_nf[r], nb = (nfu + FBh - 1) / FBh, nfp = nb * FBh;
+            const int32_t* uni_b = lg_frames.data() + r * SRK_LONG_MAXNF_HOST;
             lg_obs_off.push_back((int64_t)lg_obs.size());
-            for (size_t ck = ci; ck < cj; ++ck) {
-                const int64_t p = long_cand[ck];
+            for (int k = 0; k < lg_np[r]; ++k) {
+                const int64_t p = lg_pts[r * SRK_LONG_PTS_HOST + (size_t)k];
                 const size_t base = lg_obs.size();
                 lg_obs.resize(base + (size_t)nfp, -1);
                 for (int64_t o = rp[(size_t)p]; o < rp[(size_t)p + 1]; ++o) {
-                    const int slot = (int)(std::lower_bound(uni.begin(), uni.end(), of[(size_t)o]) - uni.begin());
+                    const int slot = (int)(std::lower_bound(uni_b, uni_b + nfu, of[(size_t)o]) - uni_b);
                     lg_obs[base + (size_t)slot] = (int32_t)o;
                 }
             }
@@ -1238,7 +1262,6 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
                 for (int b = 0; b <= a; ++b) {
                     lg_item.push_back(run); lg_item.push_back(a); lg_item.push_back(b); lg_item.push_back(0);
                 }
-            ci = cj;
         }
     }
     h->n_long_runs = (int64_t)lg_np.size();
@@ -1936,7 +1959,7 @@ static int phase_schur(srk_ba* h, double c, bool local_only)
                              P<int32_t>(h->A->irr), h->n_mm_uniform, h->n_mm_ragged, h->det_active ? &dets : nullptr);
     srk_launch_schur_long(s, d, c, P<double>(h->W), P<double>(h->Vg), P<double>(h->A->S), P<double>(h->A->rhs),
                           P<int32_t>(h->lg_item), h->n_long_items, P<int32_t>(h->lg_np), P<int32_t>(h->lg_nf), P<int32_t>(h->lg_pts),
-                          P<int32_t>(h->lg_frames), P<int64_t>(h->lg_obs_off), P<int32_t>(h->lg_obs));
+                          P<int32_t>(h->lg_frames), P<int64_t>(h->lg_obs_off), P<int32_t>(h->lg_obs), h->long_fb);
     srk_launch_schur(s, d, c, P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame), P<double>(h->W), P<double>(h->Vg),
                      P<double>(h->A->S), P<double>(h->A->rhs), P<int32_t>(h->gen_list), h->n_generic);
     HIPCHK(h, hipGetLastError());

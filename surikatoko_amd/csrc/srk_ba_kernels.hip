@@ -2121,37 +2121,40 @@ __global__ __launch_bounds__(128) void k_schur_det_gather(SrkDims d, const doubl
 // misses a frame contributes zeros there); the table `run_obs` (host) maps (landmark, frame slot) to the observation.
 // Pairs on the diagonal compute all 25 tiles and flush the lower block triangle; they also carry the block's part of
 // the right-hand side.  The sums leave as fp64 atomics, once per pair and run.
-#define SRK_LONG_FB 8
 #define SRK_LONG_RB 8     // landmarks per round
-#define SRK_LONG_LD 80    // LDS row stride in doubles (= 16 mod 32: the four k rows of an operand hit different banks)
-#define SRK_LONG_THREADS 320
-static_assert(SRK_LONG_FB * 10 == SRK_LONG_LD && SRK_LONG_LD % 16 == 0, "a frame block is a whole number of MFMA tiles");
-static_assert(SRK_LONG_THREADS / 64 * 16 == SRK_LONG_LD, "one wave per tile row");
-static_assert(2 * SRK_LONG_RB * SRK_LONG_FB * 2 <= SRK_LONG_THREADS && SRK_LONG_PTS_HOST <= SRK_LONG_THREADS, "staging lanes");
-template <typename WT>
-__global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
+// per block size FB (8 or 16 frames): NC = 10 FB columns = NC / 16 MFMA tiles exactly, one wave per tile row; the LDS row stride
+// is 16 mod 32 doubles so that the four k rows of an operand hit different banks (80; 176 for 160 columns)
+template <int FB> struct LongCfg {
+    static constexpr int NC = 10 * FB, NT = NC / 16, THREADS = 64 * NT, LD = NC % 32 == 16 ? NC : NC + 16;
+    static_assert(NC % 16 == 0 && LD % 32 == 16, "a frame block is a whole number of MFMA tiles");
+    static_assert(2 * SRK_LONG_RB * FB * 2 <= THREADS && SRK_LONG_PTS_HOST <= THREADS && 2 * NC <= THREADS, "staging lanes");
+};
+template <typename WT, int FB>
+__global__ __launch_bounds__(LongCfg<FB>::THREADS) void k_schur_long(
     SrkDims d, double c, const WT* __restrict__ W, const double* __restrict__ Vg, double* __restrict__ S,
     double* __restrict__ rhs, const int32_t* __restrict__ item /* [n][4]: run, bi, bj, - */,
     const int32_t* __restrict__ run_np, const int32_t* __restrict__ run_nf,
     const int32_t* __restrict__ run_pts /* [run][SRK_LONG_PTS] */, const int32_t* __restrict__ run_frames /* [run][SRK_LONG_MAXNF] */,
     const int64_t* __restrict__ run_obs_off, const int32_t* __restrict__ run_obs /* [off + landmark * nfp + slot] or -1 */)
 {
-    constexpr int LD = SRK_LONG_LD, RB = SRK_LONG_RB, KR = 3 * RB, BUF = KR * LD;
+    using Cfg = LongCfg<FB>;
+    constexpr int NC = Cfg::NC, NT = Cfg::NT, LD = Cfg::LD, RB = SRK_LONG_RB, KR = 3 * RB, BUF = KR * LD;
+    constexpr int HALF = RB * FB * 2; // staging lanes of a side: (landmark of the round, frame of the block, half of its ten columns)
     __shared__ __attribute__((aligned(16))) double sW[2][BUF];
     __shared__ __attribute__((aligned(16))) double sY[2][BUF];
     __shared__ __attribute__((aligned(16))) double sE[SRK_LONG_PTS_HOST][12];
-    __shared__ double sRhs[LD];
-    __shared__ int32_t sVar[2][LD]; // row / column of S of the pair's row / column e; -1: gauge-fixed or beyond the run's frames
+    __shared__ double sRhs[NC];
+    __shared__ int32_t sVar[2][NC]; // row / column of S of the pair's row / column e; -1: gauge-fixed or beyond the run's frames
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int run = item[4 * blockIdx.x], bi = item[4 * blockIdx.x + 1], bj = item[4 * blockIdx.x + 2];
     const int np = run_np[run], nf = run_nf[run];
-    const int nfp = SRK_LONG_FB * ((nf + SRK_LONG_FB - 1) / SRK_LONG_FB);
+    const int nfp = FB * ((nf + FB - 1) / FB);
     const bool diag = bi == bj;
     const int32_t* pts = run_pts + (int64_t)run * SRK_LONG_PTS_HOST;
     const int32_t* obs = run_obs + run_obs_off[run];
-    if (tid < 2 * LD) {
-        const int side = tid / LD, e = tid - side * LD;
-        const int slot = SRK_LONG_FB * (side ? bj : bi) + e / 10;
+    if (tid < 2 * NC) {
+        const int side = tid / NC, e = tid - side * NC;
+        const int slot = FB * (side ? bj : bi) + e / 10;
         int var = -1;
         if (slot < nf) {
             const int64_t v = 10 * (int64_t)run_frames[(int64_t)run * SRK_LONG_MAXNF_HOST + slot] + e % 10;
@@ -2159,7 +2162,7 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
         }
         sVar[side][e] = var;
     }
-    if (tid < LD) sRhs[tid] = 0.0;
+    if (tid < NC) sRhs[tid] = 0.0;
     if (tid < np) { // 3x3 damped block inverses; a singular block contributes nothing (:1877-1881)
         double Einv[9], g[3];
         const bool ok = point_block_inverse(Vg, d.Ns, pts[tid], c, Einv, g);
@@ -2170,10 +2173,10 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
             sE[tid][9 + m] = ok ? Einv[3 * m] * g[0] + Einv[3 * m + 1] * g[1] + Einv[3 * m + 2] * g[2] : 0.0;
     }
     // staging lane: side 0 = block bi (-> W, and Y too on a diagonal pair), side 1 = block bj (-> Y)
-    const int side = tid >> 7, within = tid & 127;
-    const int spl = within >> 4, sa = (within >> 1) & 7, sh = within & 1;
-    const bool stager = tid < 256 && (side == 0 || !diag);
-    const int sslot = SRK_LONG_FB * (side ? bj : bi) + sa;
+    const int side = tid / HALF, within = tid - side * HALF;
+    const int spl = within / (2 * FB), sa = (within >> 1) % FB, sh = within & 1;
+    const bool stager = tid < 2 * HALF && (side == 0 || !diag);
+    const int sslot = FB * (side ? bj : bi) + sa;
     const int sdst = 3 * spl * LD + 10 * sa + 5 * sh;
     double pre[15];
     auto load_round = [&](int r) { // global loads of round r into `pre` (left in flight); zeros where nothing is observed
@@ -2216,9 +2219,12 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
     load_round(0);
     __syncthreads(); // sE, sVar, sRhs
     const int lr = lane & 15, lk = lane >> 4;
-    srk_double4 acc[5];
+    // a diagonal pair needs the tiles on and below its diagonal only (S is lower-triangle authoritative; what a tile above it
+    // would add to the upper halves of the 10 x 10 diagonal blocks it cuts is never read)
+    const int tmax = diag ? __builtin_amdgcn_readfirstlane(wv) : NT - 1;
+    srk_double4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) acc[t] = (srk_double4){ 0, 0, 0, 0 };
+    for (int t = 0; t < NT; ++t) acc[t] = (srk_double4){ 0, 0, 0, 0 };
     for (int r = 0; r < R; ++r) {
         const int b = r & 1;
         stage_round(r, b);
@@ -2229,16 +2235,22 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
 #pragma unroll
         for (int ks = 0; ks < KR / 4; ++ks) {
             const double a = bw[4 * ks * LD];
-            double bb[5];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) bb[t] = by[4 * ks * LD + 16 * t];
+            for (int t0 = 0; t0 < NT; t0 += 5) { // five B operands in flight at a time
+                double bb[5];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb[t], acc[t], 0, 0, 0);
+                for (int t = 0; t < 5; ++t)
+                    if (t0 + t <= tmax) bb[t] = by[4 * ks * LD + 16 * (t0 + t)];
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    if (t0 + t <= tmax) acc[t0 + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb[t], acc[t0 + t], 0, 0, 0);
+            }
         }
     }
     // flush.  f64 16x16x4 accumulator map: column = lane & 15, row = (lane >> 4) + 4 reg
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < NT; ++t) {
+        if (t > tmax) continue;
         const int col = 16 * t + lr, vc = sVar[1][col];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -2254,22 +2266,28 @@ __global__ __launch_bounds__(SRK_LONG_THREADS) void k_schur_long(
             for (int i = 0; i < 5; ++i) atomicAdd(&sRhs[10 * sa + 5 * sh + i], racc[i]);
         }
         __syncthreads();
-        if (tid < LD && sVar[0][tid] >= 0) atomicAdd(&rhs[sVar[0][tid]], sRhs[tid]);
+        if (tid < NC && sVar[0][tid] >= 0) atomicAdd(&rhs[sVar[0][tid]], sRhs[tid]);
     }
 }
 
 void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const double* W, const double* Vg, double* S, double* rhs,
                            const int32_t* item, int64_t n_items, const int32_t* run_np, const int32_t* run_nf,
-                           const int32_t* run_pts, const int32_t* run_frames, const int64_t* run_obs_off, const int32_t* run_obs)
+                           const int32_t* run_pts, const int32_t* run_frames, const int64_t* run_obs_off, const int32_t* run_obs, int fb)
 {
     if (n_items <= 0) return;
-    if (d.w_f32)
-        hipLaunchKernelGGL(k_schur_long<float>, dim3((unsigned)n_items), dim3(SRK_LONG_THREADS), 0, s, d, c,
-                           reinterpret_cast<const float*>(W), Vg, S, rhs, item, run_np, run_nf, run_pts, run_frames, run_obs_off,
-                           run_obs);
-    else
-        hipLaunchKernelGGL(k_schur_long<double>, dim3((unsigned)n_items), dim3(SRK_LONG_THREADS), 0, s, d, c, W, Vg, S, rhs, item,
-                           run_np, run_nf, run_pts, run_frames, run_obs_off, run_obs);
+#define SRK_LONG_LAUNCH(FBV)                                                                                                       \
+    do {                                                                                                                           \
+        if (d.w_f32)                                                                                                               \
+            hipLaunchKernelGGL((k_schur_long<float, FBV>), dim3((unsigned)n_items), dim3(LongCfg<FBV>::THREADS), 0, s, d, c,         \
+                               reinterpret_cast<const float*>(W), Vg, S, rhs, item, run_np, run_nf, run_pts, run_frames, run_obs_off, \
+                               run_obs);                                                                                           \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((k_schur_long<double, FBV>), dim3((unsigned)n_items), dim3(LongCfg<FBV>::THREADS), 0, s, d, c, W, Vg, S, \
+                               rhs, item, run_np, run_nf, run_pts, run_frames, run_obs_off, run_obs);                               \
+    } while (0)
+    if (fb == 16) SRK_LONG_LAUNCH(16);
+    else SRK_LONG_LAUNCH(8);
+#undef SRK_LONG_LAUNCH
 }
 
 void srk_launch_schur_grouped(hipStream_t s, const SrkDims& d, double c, const int64_t* row_ptr, const int32_t* obs_pt,

@@ -122,7 +122,8 @@ void srk_launch_schur_long(hipStream_t s, const SrkDims& d, double c, const doub
                            int64_t n_items, const int32_t* run_np, const int32_t* run_nf,
                            const int32_t* run_pts /* [run][SRK_LONG_PTS_HOST] landmarks (internal order) */,
                            const int32_t* run_frames /* [run][SRK_LONG_MAXNF_HOST] the run's frame set, ascending */,
-                           const int64_t* run_obs_off, const int32_t* run_obs /* [off + landmark * 8 ceil(nf / 8) + slot]: observation or -1 */);
+                           const int64_t* run_obs_off, const int32_t* run_obs /* [off + landmark * fb ceil(nf / fb) + slot]: observation or -1 */,
+                           int fb = SRK_LONG_FB_HOST /* frames per block: 8 or 16 */);
 void srk_launch_assemble(hipStream_t s, const SrkDims& d, double c, const double* Ug, double* S, double* rhs,
                          double ident /* diagonal of fixed / padding variables */, const int64_t* row_ptr,
                          const int32_t* obs_frame, const double* W, const double* Vg,

@@ -1,12 +1,12 @@
 #!/bin/bash
 # development (GPU box, repo root): SQ counters of the Schur kernels over a few Schur phases of C3
-# usage: tools/schur_pmc.sh "<counter list 1>" "<counter list 2>" ...   (one rocprofv3 pass per list)
+# usage: [SRK_PMC_CONFIG=C2_all_visible] tools/schur_pmc.sh "<counter list 1>" "<counter list 2>" ...   (one rocprofv3 pass per list)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 cat > tools/_schur_only.py <<'PY'
 import sys, os; sys.path.insert(0, os.getcwd())
 import surikatoko_amd as sa
-spec=sa.CONFIGS["C3_1kcam_100kpt"]; sc=sa.generate_scene(spec)
+spec=sa.CONFIGS[os.environ.get("SRK_PMC_CONFIG", "C3_1kcam_100kpt")]; sc=sa.generate_scene(spec)
 ba=sa.BundleAdjustmentKanatani(0); ba.upload(spec.f0, sc)
 ba.phase_error(); ba.phase_derivatives()
 for _ in range(4): ba.phase_schur(1e-4)
