@@ -272,7 +272,8 @@ int64_t srk_ba_iteration_log(srk_ba*, int64_t cap, int32_t* attempts, double* ms
  * (srk_ba_set_profile 0, the default) the LM loop runs the next damping factor on a second stream beside the current
  * one and judges the attempts in the reference's order, so results are those of the sequential loop; costs a second
  * reduced camera system in memory.  With several ranks every rank takes the same decisions, so the exchanges of the
- * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time. */
+ * two attempts are issued in the same order everywhere.  0 = strictly one attempt at a time -- with several ranks too: one
+ * attempt slot, i.e. the all-reduce schedule without pairs (the damping-parallel schedule runs two or three factors a round). */
 int srk_ba_set_speculation(srk_ba*, int on);
 
 /* Deterministic mode (default off; takes effect at the next upload).  The reference is sequential: it adds every landmark's

@@ -1514,7 +1514,9 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
     } while (0)
     // several ranks, damping-parallel schedule: one slot per damping factor of a round (at most three)
     const bool multi_upload = h->allreduce || h->comm;
-    const int n_slots = (multi_upload && h->dp_schedule && (h->world >= 2 || h->dp_force))
+    // (srk_ba_set_speculation(h, 0) = strictly one attempt at a time, with several ranks as well: one slot, hence the
+    // all-reduce schedule without pairs)
+    const int n_slots = (multi_upload && h->dp_schedule && h->speculate && (h->world >= 2 || h->dp_force))
                             ? (h->dp_force ? SRK_SLOTS : std::min(SRK_SLOTS, h->world))
                             : (h->speculate ? 2 : 1);
     for (int w = 0; w < SRK_SLOTS + 1; ++w) {
