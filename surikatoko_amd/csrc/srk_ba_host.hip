@@ -76,6 +76,11 @@ struct srk_ba {
     bool jac_fused = false; // every 1024-observation workgroup touches < SRK_JF_SLOTS_HOST consecutive frames
     // run-based Jacobian kernel (k_jac_runs): tasks = pieces of runs of landmarks with identical frame lists
     DevBuf jr_first, jr_count, jr_jmin, jr_group;
+    // the derivative kernel's OWN runs (round 4): when a scene holds tracks over more than SRK_GRP_MAXNF_HOST frames the Schur
+    // kernels' runs do not cover every landmark; runs over unions of <= 32 frames (one mask word) built for the derivative kernel
+    // alone do, as long as no track is longer than that
+    DevBuf jd_nf, jd_frames, jd_mask;
+    bool jr_own_runs = false;
     // deterministic mode (srk_ba_set_deterministic; srk_dev.hpp: SrkDetJac / SrkDetSchur): index tables of the ordered second
     // passes and the derivative kernel's staging buffer (the Schur kernel's are per attempt slot)
     bool deterministic = false;       // asked for (takes effect at the next upload)
@@ -349,6 +354,7 @@ void srk_ba_destroy(srk_ba* h)
                       &h->scratch, &h->grp_first, &h->grp_count, &h->grp_nf, &h->grp_frames, &h->obs_slot, &h->pt_mask,
                       &h->gen_list, &h->env_col, &h->env_off, &h->wg_jmin, &h->band_col, &h->band_off,
                       &h->dj_ptr, &h->dj_ent, &h->dj_stage, &h->ds_pair_ptr, &h->ds_pair_fa, &h->ds_pair_fb, &h->ds_pair_ent, &h->ds_f_ptr, &h->ds_f_ent,
+                      &h->jd_nf, &h->jd_frames, &h->jd_mask,
                       &h->jr_first, &h->jr_count, &h->jr_jmin, &h->jr_group, &h->lg_item, &h->lg_np, &h->lg_nf, &h->lg_pts, &h->lg_frames,
                       &h->lg_obs_off, &h->lg_obs };
     for (DevBuf* b : all) dev_free(*b);
@@ -1380,20 +1386,71 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
     // kernel with a lane per (landmark, frame slot) CELL: tasks = pieces of those runs.  Needs every landmark in a run.
     std::vector<int32_t> jr_group;
     h->jac_runs_masked = false;
-    if ((!h->jac_runs || h->jac_mode == 2) && h->jac_mode != 0 && O < (int64_t)1 << 27 && long_cand.empty() && gen_list.empty() && !grp_first.empty()) {
+    // The runs the union tasks are pieces of: the Schur kernels' (every landmark is in one when no track is longer than
+    // SRK_GRP_MAXNF_HOST frames), else runs of the derivative kernel's own over unions of <= 32 frames (a lane's observation is
+    // found from a 32-bit mask), when no track is longer than that.
+    std::vector<int32_t> jd_first, jd_count, jd_nf, jd_frames;
+    std::vector<uint32_t> jd_mask;
+    h->jr_own_runs = false;
+    constexpr int JD_MAXNF = 32;
+    if ((!h->jac_runs || h->jac_mode == 2) && h->jac_mode != 0 && O < (int64_t)1 << 27 && !long_cand.empty() && gen_list.empty()) {
+        bool fits = true;
+        for (int32_t p : long_cand) fits = fits && rp[(size_t)p + 1] - rp[(size_t)p] <= JD_MAXNF;
+        if (fits) {
+            jd_mask.assign((size_t)N, 0);
+            std::vector<int32_t> uni, merged;
+            for (int64_t i = 0; i < N;) {
+                const int64_t nfi = rp[(size_t)i + 1] - rp[(size_t)i];
+                if (nfi == 0) { ++i; continue; }
+                uni.assign(of.begin() + rp[(size_t)i], of.begin() + rp[(size_t)i + 1]);
+                int64_t j = i + 1;
+                while (j < N && j - i < SRK_GRP_MAXPTS_HOST) {
+                    const int64_t nfj = rp[(size_t)j + 1] - rp[(size_t)j];
+                    if (nfj == 0) break;
+                    if (nfj == (int64_t)uni.size() && std::equal(uni.begin(), uni.end(), of.begin() + rp[(size_t)j])) { ++j; continue; }
+                    merged.clear();
+                    std::set_union(uni.begin(), uni.end(), of.begin() + rp[(size_t)j], of.begin() + rp[(size_t)j + 1], std::back_inserter(merged));
+                    if ((int64_t)merged.size() > JD_MAXNF) break;
+                    if (merged.size() > uni.size() && j - i >= 24) break; // (a wider set costs every landmark of the run lanes)
+                    uni.swap(merged);
+                    ++j;
+                }
+                bool uniform = true;
+                for (int64_t p = i; p < j; ++p) {
+                    uint32_t mask = 0;
+                    for (int64_t o = rp[(size_t)p]; o < rp[(size_t)p + 1]; ++o)
+                        mask |= 1u << (int)(std::lower_bound(uni.begin(), uni.end(), of[(size_t)o]) - uni.begin());
+                    uniform = uniform && rp[(size_t)p + 1] - rp[(size_t)p] == (int64_t)uni.size();
+                    jd_mask[(size_t)p] = mask;
+                }
+                jd_first.push_back((int32_t)i);
+                jd_count.push_back((int32_t)(j - i));
+                jd_nf.push_back(uniform ? (int32_t)uni.size() : -(int32_t)uni.size());
+                for (int k = 0; k < JD_MAXNF; ++k) jd_frames.push_back(k < (int)uni.size() ? uni[(size_t)k] : -1);
+                i = j;
+            }
+            h->jr_own_runs = true;
+        }
+    }
+    const std::vector<int32_t>& rn_first = h->jr_own_runs ? jd_first : grp_first;
+    const std::vector<int32_t>& rn_count = h->jr_own_runs ? jd_count : grp_count;
+    const std::vector<int32_t>& rn_nf = h->jr_own_runs ? jd_nf : grp_nf;
+    const std::vector<int32_t>& rn_frames = h->jr_own_runs ? jd_frames : grp_frames;
+    const size_t rn_stride = h->jr_own_runs ? (size_t)JD_MAXNF : (size_t)SRK_GRP_MAXNF_HOST;
+    if ((!h->jac_runs || h->jac_mode == 2) && h->jac_mode != 0 && O < (int64_t)1 << 27 && (h->jr_own_runs || long_cand.empty()) && gen_list.empty() && !rn_first.empty()) {
         const bool uniform_ok = h->jac_runs; // (mode 2: the union tasks are preferred, the uniform ones stay as the fallback)
         std::vector<int32_t> u_first, u_count, u_jmin;
         u_first.swap(jr_first); u_count.swap(jr_count); u_jmin.swap(jr_jmin);
         jr_first.clear();
         jr_count.clear();
         jr_jmin.clear();
-        for (size_t gi = 0; gi < grp_first.size(); ++gi) {
-            const int64_t nfu = std::abs(grp_nf[gi]), g = 64 / nfu, len = grp_count[gi];
+        for (size_t gi = 0; gi < rn_first.size(); ++gi) {
+            const int64_t nfu = std::abs(rn_nf[gi]), g = 64 / nfu, len = rn_count[gi];
             const int64_t most = SRK_JR_TASK_PTS_MAX_HOST / g * g;
             const int64_t pieces = std::max<int64_t>((len + most - 1) / most, (len + jr_piece_target / 2) / jr_piece_target);
             const int64_t piece = std::max<int64_t>(g, ((len + pieces - 1) / pieces + g - 1) / g * g);
             for (int64_t a = 0; a < len; a += piece) {
-                jr_first.push_back(grp_first[gi] + (int32_t)a);
+                jr_first.push_back(rn_first[gi] + (int32_t)a);
                 jr_count.push_back((int32_t)std::min<int64_t>(piece, len - a));
                 jr_group.push_back((int32_t)gi);
             }
@@ -1403,8 +1460,8 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
             int32_t lo = M, hi = -1;
             for (size_t t = t0; t < std::min(jr_first.size(), t0 + 4); ++t) {
                 const size_t gi = (size_t)jr_group[t];
-                lo = std::min(lo, grp_frames[gi * SRK_GRP_MAXNF_HOST]);
-                hi = std::max(hi, grp_frames[gi * SRK_GRP_MAXNF_HOST + (size_t)std::abs(grp_nf[gi]) - 1]);
+                lo = std::min(lo, rn_frames[gi * rn_stride]);
+                hi = std::max(hi, rn_frames[gi * rn_stride + (size_t)std::abs(rn_nf[gi]) - 1]);
             }
             if (hi - lo >= SRK_JF_SLOTS_HOST) ok = false;
             jr_jmin.push_back(lo);
@@ -1414,6 +1471,7 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
             jr_first.swap(u_first); jr_count.swap(u_count); jr_jmin.swap(u_jmin);
             jr_group.clear();
             h->jac_runs = uniform_ok;
+            h->jr_own_runs = false;
         } else
             h->jac_runs = true;
     }
@@ -1599,6 +1657,11 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
         ALLOC(h->ds_f_ptr, 4 * ds_f_ptr.size());
         ALLOC(h->ds_f_ent, 4 * std::max<size_t>(ds_f_ent.size(), 1));
     }
+    if (h->jr_own_runs) {
+        ALLOC(h->jd_nf, 4 * jd_nf.size());
+        ALLOC(h->jd_frames, 4 * jd_frames.size());
+        ALLOC(h->jd_mask, 4 * jd_mask.size());
+    }
 #undef ALLOC
     hipStream_t s = h->stream;
     stage("device allocations");
@@ -1620,6 +1683,11 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
     H2D(h->col_ptr, col_ptr.data(), 8 * ((int64_t)M + 1));
     H2D(h->fobs_pt, fobs_pt.data(), 4 * fobs_pt.size());
     H2D(h->fobs_uv, fobs_uv.data(), 8 * fobs_uv.size());
+    if (h->jr_own_runs) {
+        H2D(h->jd_nf, jd_nf.data(), 4 * jd_nf.size());
+        H2D(h->jd_frames, jd_frames.data(), 4 * jd_frames.size());
+        H2D(h->jd_mask, jd_mask.data(), 4 * jd_mask.size());
+    }
     if (h->det_active) {
         H2D(h->dj_ptr, dj_ptr.data(), 4 * dj_ptr.size());
         H2D(h->dj_ent, dj_ent.data(), 4 * dj_ent.size());
@@ -1903,8 +1971,11 @@ static int phase_derivatives(srk_ba* h)
         srk_launch_jac_runs(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int64_t>(h->row_ptr), P<int32_t>(h->obs_frame),
                             P<double>(h->obs_uv), P<double>(h->W), P<double>(h->Vg), P<double>(h->Ug), P<int32_t>(h->jr_first),
                             P<int32_t>(h->jr_count), h->jr_tasks, P<int32_t>(h->jr_jmin),
-                            h->jac_runs_masked ? P<int32_t>(h->jr_group) : nullptr, P<int32_t>(h->grp_nf), P<int32_t>(h->grp_frames),
-                            P<uint32_t>(h->pt_mask), h->det_active ? &detj : nullptr);
+                            h->jac_runs_masked ? P<int32_t>(h->jr_group) : nullptr,
+                            h->jr_own_runs ? P<int32_t>(h->jd_nf) : P<int32_t>(h->grp_nf),
+                            h->jr_own_runs ? P<int32_t>(h->jd_frames) : P<int32_t>(h->grp_frames),
+                            h->jr_own_runs ? P<uint32_t>(h->jd_mask) : P<uint32_t>(h->pt_mask), h->det_active ? &detj : nullptr,
+                            h->jr_own_runs ? 32 : SRK_GRP_MAXNF_HOST);
         if (h->profile_level >= 1) HIPCHK(h, hipEventRecord(h->ev[13], s));
     } else if (h->jac_fused) {
         srk_launch_jac_fused(s, d, P<double>(h->pts[c]), P<double>(h->cam[c]), P<int32_t>(h->obs_frame),

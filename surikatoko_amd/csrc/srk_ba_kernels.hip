@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
                                                      const int32_t* __restrict__ wg_jmin,
                                                      const int32_t* __restrict__ task_group, const int32_t* __restrict__ grp_nf,
                                                      const int32_t* __restrict__ grp_frames, const uint32_t* __restrict__ pt_mask,
-                                                     double* __restrict__ det_stage /* DET: [task][64][SRK_UG] */)
+                                                     double* __restrict__ det_stage /* DET: [task][64][SRK_UG] */, int frames_stride)
 {
     __shared__ int32_t sTOff[MASKED ? 4 : 1][MASKED ? SRK_JR_TASK_PTS_MAX_HOST : 1];
     __shared__ uint32_t sTMask[MASKED ? 4 : 1][MASKED ? SRK_JR_TASK_PTS_MAX_HOST : 1];
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_jac_runs(SrkDims d, const double* __
         if constexpr (MASKED) {
             const int gi = task_group[task];
             nf = grp_nf[gi] < 0 ? -grp_nf[gi] : grp_nf[gi];
-            fr = grp_frames + (int64_t)gi * SRK_GRP_MAXNF_HOST;
+            fr = grp_frames + (int64_t)gi * frames_stride;
             for (int l = lane; l < n_pts; l += WAVE) {
                 sTOff[wv][l] = (int32_t)(row_ptr[first_pt + l] - o_base);
                 sTMask[wv][l] = pt_mask[first_pt + l];
@@ -671,11 +671,11 @@ void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, con
                          const int32_t* obs_frame, const double* obs_uv, double* W, double* Vg, double* Ug,
                          const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
                          const int32_t* task_group, const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask,
-                         const SrkDetJac* det)
+                         const SrkDetJac* det, int frames_stride)
 {
     if (n_tasks <= 0) return;
     const dim3 grid((unsigned)((n_tasks + 3) / 4));
-#define SRK_JR_ARGS(WP) d, pts, cam, row_ptr, obs_frame, obs_uv, WP, Vg, Ug, task_first, task_count, n_tasks, wg_jmin, task_group, grp_nf, grp_frames, pt_mask, det ? det->stage : nullptr
+#define SRK_JR_ARGS(WP) d, pts, cam, row_ptr, obs_frame, obs_uv, WP, Vg, Ug, task_first, task_count, n_tasks, wg_jmin, task_group, grp_nf, grp_frames, pt_mask, det ? det->stage : nullptr, frames_stride
 #define SRK_JR_LAUNCH(MASKED)                                                                                                         \
     do {                                                                                                                              \
         if (det) {                                                                                                                    \

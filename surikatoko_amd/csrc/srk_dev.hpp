@@ -87,7 +87,8 @@ void srk_launch_jac_runs(hipStream_t s, const SrkDims& d, const double* pts, con
                          const int32_t* task_first, const int32_t* task_count, int32_t n_tasks, const int32_t* wg_jmin,
                          const int32_t* task_group /* NULL: uniform runs; else the Schur run (grp_*) each task is a piece of */,
                          const int32_t* grp_nf, const int32_t* grp_frames, const uint32_t* pt_mask,
-                         const SrkDetJac* det = nullptr /* deterministic mode */);
+                         const SrkDetJac* det = nullptr /* deterministic mode */,
+                         int frames_stride = 24 /* row length of grp_frames: SRK_GRP_MAXNF_HOST (the Schur runs) or 32 (the derivative kernel's own) */);
 void srk_launch_jac_frames(hipStream_t s, const SrkDims& d, int64_t max_frame_obs, const double* pts,
                            const double* cam, const int64_t* col_ptr, const int32_t* fobs_pt, const double* fobs_uv,
                            double* Ug);

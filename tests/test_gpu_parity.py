@@ -310,6 +310,11 @@ UNION_RUN_SCENES = {
     "uniform_nf16": lambda: sa.generate_scene(JAC_RUN_SCENES["nf16"]),             # full masks: the uniform case of the same code
     "uniform_nf3": lambda: sa.generate_scene(JAC_RUN_SCENES["nf3_many_per_iteration"]),
     "two_observations_each": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=20, grid_nx=15, grid_ny=12, vis_window=9)), 0.9, seed=1),
+    # tracks over 25 .. 32 frames (round 4): the Schur sums take k_schur_long's runs, which do not cover the shorter tracks --
+    # the derivative kernel forms runs of its own over unions of <= 32 frames (one mask word)
+    "ragged_28_own_runs": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=48, grid_nx=40, grid_ny=30, vis_window=28, noise_uv_pix=0.3)), 0.15, seed=9),
+    "mixed_12_to_30_own_runs": lambda: sa.drop_observations(sa.generate_scene(sa.SceneSpec(n_frames=48, grid_nx=40, grid_ny=30, vis_window=30)), 0.35, seed=11),
+    "uniform_nf32_own_runs": lambda: sa.generate_scene(sa.SceneSpec(n_frames=40, grid_nx=30, grid_ny=20, vis_window=32)),
 }
 
 
@@ -323,6 +328,8 @@ def test_run_based_derivative_kernel_over_frame_unions_vs_oracle(orc, gpu, name,
     try:
         out = _phases(orc, gpu, sc, 600.0, c)
         assert gpu.jacobian_kernel() == 3
+        if name.endswith("own_runs"):
+            assert np.diff(sc.row_ptr).max() > 24        # some tracks are beyond the Schur kernels' runs
         _check(out, sc.M, corr_tol=1e-7)
     finally:
         gpu.set_jacobian_mode(-1)
