@@ -143,6 +143,28 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][
                 a[m] = fma(-zp3, y23.y, fma(-zp2, y23.x, fma(-zp1, y01.y, fma(-zp0, y01.x, a[m]))));
             }
         }
+#ifndef SRK_POTRF_SEQ_PIVOTS
+        // The four pivots in TWO reciprocal stages instead of four (round 4): the second pivot of a pair is a quotient of
+        // determinants, u11 = (d00 d11 - d10^2) / d00, so 1 / u11 = d00 / det starts beside 1 / d00 instead of behind it (the
+        // subtraction cancels exactly as d11 - d10^2 / d00 does: same relative error eps d11 / u11); likewise 1 / u33 beside
+        // 1 / u22 on the Schur complement of the first pair.  A group's chain is bound by these dependent reciprocals.
+        const double u00 = d0.x, u10 = d1.x, u20 = d2a.x, u30 = d3a.x;
+        const double det01 = fma(u00, d1.y, -(u10 * u10));
+        const double r0 = SRK_POTRF_RCP(u00);
+        const double r1 = u00 * SRK_POTRF_RCP(det01);
+        const double l20 = u20 * r0, l30 = u30 * r0;
+        const double u21 = fma(-l20, u10, d2a.y), u31 = fma(-l30, u10, d3a.y);
+        const double l21 = u21 * r1, l31 = u31 * r1;
+        const double u22 = fma(-l21, u21, fma(-l20, u20, d2b.x));
+        const double u32 = fma(-l31, u21, fma(-l30, u20, d3b.x));
+        const double u33p = fma(-l31, u31, fma(-l30, u30, d3b.y)); // u33 before the last pivot's term
+        const double det23 = fma(u22, u33p, -(u32 * u32));
+        const double r2 = SRK_POTRF_RCP(u22);
+        const double r3 = u22 * SRK_POTRF_RCP(det23);
+        // pivot health: u11 and u33 have the sign of their determinants (given the pivot before them is positive)
+        dmin = fmin(fmin(dmin, u00), fmin(det01, fmin(u22, det23)));
+        dchk = fma(0.0, u00, fma(0.0, det01, fma(0.0, u22, fma(0.0, det23, dchk))));
+#else
         const double u00 = d0.x;
         const double r0 = SRK_POTRF_RCP(u00);
         const double u10 = d1.x, u20 = d2a.x, u30 = d3a.x;
@@ -159,6 +181,7 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][
         const double r3 = SRK_POTRF_RCP(u33);
         dmin = fmin(fmin(dmin, u00), fmin(u11, fmin(u22, u33)));
         dchk = fma(0.0, u00, fma(0.0, u11, fma(0.0, u22, fma(0.0, u33, dchk))));
+#endif
         // ---- B: this row against the factor.  y_k = p_k - sum_{k' < k} (y_k' / d_k') u_kk'
         const double p0 = quad_bcast<0>(a[g]), p1 = quad_bcast<1>(a[g]), p2 = quad_bcast<2>(a[g]), p3 = quad_bcast<3>(a[g]);
         const double y0 = p0, z0 = y0 * r0;
