@@ -111,7 +111,7 @@ __device__ __forceinline__ double fast_rcp1(double d)
 #define SRK_POTRF_RCP fast_rcp1
 #endif
 // PUB (the diagonal-block workgroup of k_step256, whose other waves carry passenger rows): the threads also publish every
-// group's 4 x 4 factor (u_jk below the diagonal, 1 / d_k) in sF [2][64] before the group's SECOND barrier, and 1 / sqrt(d) in sRsq.
+// group's 4 x 4 factor (multipliers l_jk = u_jk / d_k below the diagonal, 1 / d_k) in sF [2][64] before the group's SECOND barrier, and 1 / sqrt(d) in sRsq.
 template <bool PUB>
 __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][64][4]: panel P, finals Y (two buffers)*/,
                                         double* sDiag /*[64]*/, double* sInv /*[64]*/, double* sF, double* sRsq)
@@ -184,10 +184,22 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][
 #endif
         // ---- B: this row against the factor.  y_k = p_k - sum_{k' < k} (y_k' / d_k') u_kk'
         const double p0 = quad_bcast<0>(a[g]), p1 = quad_bcast<1>(a[g]), p2 = quad_bcast<2>(a[g]), p3 = quad_bcast<3>(a[g]);
+#ifndef SRK_POTRF_SEQ_PIVOTS
+        // (with the factor's multipliers l_jk = u_jk / d_k -- the same for every row -- a row's chain is three dependent
+        // multiply-adds instead of seven operations; its own multipliers z_k = y_k / d_k follow in parallel)
+        const double m10 = u10 * r0, m32 = u32 * r2;
+        const double y0 = p0;
+        const double y1 = fma(-y0, m10, p1);
+        const double y2 = fma(-y1, l21, fma(-y0, l20, p2));
+        const double y3 = fma(-y2, m32, fma(-y1, l31, fma(-y0, l30, p3)));
+        const double z0 = y0 * r0, z1 = y1 * r1, z2 = y2 * r2, z3 = y3 * r3;
+#else
+        const double m10 = u10 * r0, m32 = u32 * r2;
         const double y0 = p0, z0 = y0 * r0;
         const double y1 = fma(-z0, u10, p1), z1 = y1 * r1;
         const double y2 = fma(-z1, u21, fma(-z0, u20, p2)), z2 = y2 * r2;
         const double y3 = fma(-z2, u32, fma(-z1, u31, fma(-z0, u30, p3))), z3 = y3 * r3;
+#endif
         {
             const double y01 = (q & 1) ? y1 : y0, y23 = (q & 1) ? y3 : y2;
             a[g] = (q & 2) ? y23 : y01; // final (unscaled) entry of column 4g + q
@@ -197,8 +209,8 @@ __device__ __forceinline__ bool potrf64(double (*sD)[NB + 2], double* sPY /*[3][
         // for LDS anyway (the last reciprocal is not needed before it)
         if (PUB) {
             const int l = t & 63;
-            fv = u10;
-            fv = l == 1 ? u20 : fv, fv = l == 2 ? u30 : fv, fv = l == 3 ? u21 : fv, fv = l == 4 ? u31 : fv, fv = l == 5 ? u32 : fv;
+            fv = m10; // the factor's multipliers l_jk = u_jk / d_k (what a row's elimination multiplies by)
+            fv = l == 1 ? l20 : fv, fv = l == 2 ? l30 : fv, fv = l == 3 ? l21 : fv, fv = l == 4 ? l31 : fv, fv = l == 5 ? m32 : fv;
             fv = l == 6 ? r0 : fv, fv = l == 7 ? r1 : fv, fv = l == 8 ? r2 : fv, fv = l == 9 ? r3 : fv;
             if (g == 15) sF[64 * (g & 1) + l] = fv;
         }
@@ -769,15 +781,16 @@ template <int NP> __device__ __forceinline__ void passenger_group(double (&a)[3]
 #pragma unroll
     for (int k = 0; k < H; ++k)
         if (g + 1 + k < 16) ya[k] = sY[2 * 4 * (g + 1 + k)], yb[k] = sY[2 * 4 * (g + 1 + k) + 1];
-    const double u10 = f0.x, u20 = f0.y, u30 = f1.x, u21 = f1.y, u31 = f2.x, u32 = f2.y, r0 = f3.x, r1 = f3.y, r2 = f4.x, r3 = f4.y;
+    const double l10 = f0.x, l20 = f0.y, l30 = f1.x, l21 = f1.y, l31 = f2.x, l32 = f2.y, r0 = f3.x, r1 = f3.y, r2 = f4.x, r3 = f4.y;
     double z[NP > 0 ? NP : 1][4];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const double p0 = quad_bcast<0>(a[p][g]), p1 = quad_bcast<1>(a[p][g]), p2 = quad_bcast<2>(a[p][g]), p3 = quad_bcast<3>(a[p][g]);
-        const double y0 = p0, z0 = y0 * r0;
-        const double y1 = fma(-z0, u10, p1), z1 = y1 * r1;
-        const double y2 = fma(-z1, u21, fma(-z0, u20, p2)), z2 = y2 * r2;
-        const double y3 = fma(-z2, u32, fma(-z1, u31, fma(-z0, u30, p3))), z3 = y3 * r3;
+        const double y0 = p0;
+        const double y1 = fma(-y0, l10, p1);
+        const double y2 = fma(-y1, l21, fma(-y0, l20, p2));
+        const double y3 = fma(-y2, l32, fma(-y1, l31, fma(-y0, l30, p3)));
+        const double z0 = y0 * r0, z1 = y1 * r1, z2 = y2 * r2, z3 = y3 * r3;
         const double y01 = (q & 1) ? y1 : y0, y23 = (q & 1) ? y3 : y2;
         a[p][g] = (q & 2) ? y23 : y01; // final (unscaled) entry of column 4g + q
         z[p][0] = z0, z[p][1] = z1, z[p][2] = z2, z[p][3] = z3;
