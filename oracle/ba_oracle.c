@@ -39,8 +39,8 @@ void orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; }
  * the 1000-camera scene can be timed on the CPU.  Never set by a test; results are meaningless while it is on. */
 /* f32 storage mode of the HIP path (srk_ba_set_storage_precision): the point-frame blocks are rounded to float where the
  * derivative pass stores them; everything computed from them afterwards sees the rounded values.  Off by default. */
-static int orc_w_f32 = 0;
-void orc_set_w_storage_f32(int on) { orc_w_f32 = on != 0; }
+static int orc_w_f32 = 0; /* 0: off; 1: the 30 products of a point-frame block rounded to float once; 2: the rank-2 FACTORS rounded */
+void orc_set_w_storage_f32(int mode) { orc_w_f32 = mode == 2 ? 2 : (mode != 0); }
 static int orc_skip_solve = 0;
 void orc_set_skip_solve(int on) { orc_skip_solve = on != 0; }
 int orc_get_threads(void) { return orc_threads; }
@@ -810,6 +810,25 @@ void orc_derivatives(double f0, int64_t N, const double* points, int32_t M, cons
                         second_deriv(pqr, fd[v1][0], fd[v1][1], fd[v1][2], fd[v2][0], fd[v2][1], fd[v2][2]);
             point_pqr_derivs(Kj, R, pd);
             double* W = Wpf + 30 * o;
+            if (orc_w_f32 == 2) {
+                /* what the HIP path's f32 storage mode keeps: formula 9 is W[pv][fv] = Ap[pv] Af[fv] + Bp[pv] Bf[fv] with
+                 * A(v) = (r p' - p r') sqrt(2) / r^2, B(v) = (r q' - q r') sqrt(2) / r^2 (BA:1540-1549 regrouped); the
+                 * library stores those FACTORS as floats and forms the products in double */
+                const double sc = 1.4142135623730951 / (pqr[2] * pqr[2]);
+                float Apf[3], Bpf[3], Aff[10], Bff[10];
+                for (int pv = 0; pv < 3; ++pv) {
+                    Apf[pv] = (float)((pqr[2] * pd[pv][0] - pqr[0] * pd[pv][2]) * sc);
+                    Bpf[pv] = (float)((pqr[2] * pd[pv][1] - pqr[1] * pd[pv][2]) * sc);
+                }
+                for (int fv = 0; fv < 10; ++fv) {
+                    Aff[fv] = (float)((pqr[2] * fd[fv][0] - pqr[0] * fd[fv][2]) * sc);
+                    Bff[fv] = (float)((pqr[2] * fd[fv][1] - pqr[1] * fd[fv][2]) * sc);
+                }
+                for (int pv = 0; pv < 3; ++pv)
+                    for (int fv = 0; fv < 10; ++fv)
+                        W[10 * pv + fv] += (double)Apf[pv] * (double)Aff[fv] + (double)Bpf[pv] * (double)Bff[fv];
+                continue;
+            }
             for (int pv = 0; pv < 3; ++pv)
                 for (int fv = 0; fv < 10; ++fv)
                     W[10 * pv + fv] +=
@@ -817,7 +836,7 @@ void orc_derivatives(double f0, int64_t N, const double* points, int32_t M, cons
         }
     }
     csc_free(&c);
-    if (orc_w_f32)
+    if (orc_w_f32 == 1)
         for (int64_t e = 0; e < 30 * O; ++e) Wpf[e] = (double)(float)Wpf[e];
 }
 

@@ -260,9 +260,10 @@ def set_threads(n):
     lib().orc_set_threads(C.c_int(int(n)))
 
 
-def set_w_storage_f32(on):
-    """Round the point-frame blocks to float where they are stored (the HIP path's f32 storage mode)."""
-    lib().orc_set_w_storage_f32(C.c_int(int(bool(on))))
+def set_w_storage_f32(mode):
+    """0 / False: off; 1 / True: the 30 products of every point-frame block rounded to float once; 2: its rank-2 FACTORS rounded
+    to float and the products formed in double -- what the HIP path's f32 storage mode stores"""
+    lib().orc_set_w_storage_f32(C.c_int(2 if mode == 2 else int(bool(mode))))
 
 
 def set_skip_solve(on):

@@ -9,7 +9,7 @@
 //            frame-major copy:  col_ptr[M+1] i64, fobs_pt[O] i32, fobs_uv[O][2]
 //   W        fp64 storage (default): [21][Os] the rank-2 FACTORS of the point-frame blocks (SRK_WF_* below), structure-of-
 //            arrays, plane k of observation o at W[k*Os + o] (Os = O rounded up to 64): every store/load is lane-contiguous;
-//            f32 storage mode: [30][Os] floats, element k = 10*pv + fv of observation o at W[k*Os + o]
+//            f32 storage mode: the same 21 planes as floats ([21][Os], plane k of observation o at W[k*Os + o]); widened on load
 //   Vg       [9][Ns]   per point: V00 V01 V02 V11 V12 V22 g0 g1 g2 (SoA, Ns = N rounded up to 64)
 //   Ug       [M][65]   per frame: 55 upper-triangle entries of the 10x10 block (row-major order) + 10 gradient
 //   S        [ld][ld]  padded reduced camera system, row-major, LOWER triangle authoritative;

@@ -1291,6 +1291,36 @@ def test_fused_outer_step_is_reproducible_and_agrees_with_the_panel_sequence_den
         gpu.set_solver_fusion(1)
 
 
+@pytest.mark.parametrize("cond", [1e6, 1e10, 1e13])
+def test_solver_is_backward_stable_on_ill_conditioned_systems(gpu, cond):
+    """potrf64's pivot reciprocals take ONE Newton step on the v_rcp_f64 seed (2e-15 relative) and, since round 4, the second
+    pivot of a pair as a quotient of determinants: neither may cost backward stability.  Dense SPD systems with a prescribed
+    spectrum (condition 1e6 .. 1e13, eigenvalues geometrically spaced, random orthogonal basis), 640 variables = three outer
+    steps, fused and unfused: the normwise backward error ||A x - b|| / (||A|| ||x|| + ||b||) stays at n eps, the forward
+    error within cond x that (a Cholesky that lost digits in its pivots would show in the first; LAPACK's own solve is the
+    yardstick for the second)."""
+    rng = np.random.RandomState(11)
+    n = 640
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    lam = np.geomspace(1.0, 1.0 / cond, n)
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    x_true = rng.randn(n)
+    b = A @ x_true
+    try:
+        for fused in (1, 0):
+            gpu.set_solver_fusion(fused)
+            ok, x, _ = gpu.dense_spd_solve(A, b)
+            assert ok
+            berr = np.linalg.norm(A @ x - b) / (np.linalg.norm(A, 2) * np.linalg.norm(x) + np.linalg.norm(b))
+            assert berr < 50 * n * np.finfo(np.float64).eps / 8, (fused, berr)     # ~ 9e-13 / 8: a few n eps
+            x_lapack = np.linalg.solve(A, b)
+            ferr, ferr_lapack = np.linalg.norm(x - x_true) / np.linalg.norm(x_true), np.linalg.norm(x_lapack - x_true) / np.linalg.norm(x_true)
+            assert ferr < max(20 * ferr_lapack, 1e-13), (fused, ferr, ferr_lapack)
+    finally:
+        gpu.set_solver_fusion(1)
+
+
 @pytest.mark.parametrize("n_frames,window", [(103, 8), (330, 8), (500, 30), (800, 95)])
 def test_fused_outer_step_is_reproducible_and_agrees_with_the_panel_sequence_chunked(gpu, n_frames, window):
     """The same on nested chunks with 256- to 1024-wide separators (batched items, border rows, structurally zero border
@@ -1567,10 +1597,12 @@ def test_f32_storage_mode_tolerance_table(orc, name):
     """srk_ba_set_storage_precision(1): the rank-2 factors of the point-frame blocks W are stored as float (half the bytes of
     what the derivative pass writes and the Schur and back-substitution passes read), widened on load; sums, reduced camera
     system and solve stay fp64.  Tolerance table:
-      against the ORACLE WITH ITS W ROUNDED TO FLOAT (orc.set_w_storage_f32: the 30 products rounded once; the library rounds
-        the two factors of each product): W within 2.5e-7 of the block scale (two float roundings and a sum), reduced
-        system 6e-7, the LM loop with the same accept / reject sequence and error rel 1e-5 -- i.e. the mode is the fp64
-        algorithm on W blocks a few float ulps away;
+      against the ORACLE WITH THE SAME FACTORS ROUNDED TO FLOAT (orc.set_w_storage_f32(2), round 4: formula 9 regrouped as
+        Ap Af + Bp Bf, the four factors rounded, the products formed in double -- exactly what the library stores): W equal to
+        1e-12 of the block scale in all but a handful of entries (a factor whose double value sits within an ulp of a float
+        rounding boundary can round the other way on the two sides: at most two flipped factors an entry, 1.3e-7), reduced
+        system 1e-9, the LM loop with the same accept / reject sequence and error rel 1e-6 -- i.e. the mode IS the fp64
+        algorithm on identically rounded W;
       against the fp64 path: W 2.5e-7, reduced system 1.5e-6 of its largest entry, one-step corrections 1e-3, error rel 1e-4."""
     spec = F32_SCENES[name]
     sc = sa.generate_scene(spec)
@@ -1579,20 +1611,22 @@ def test_f32_storage_mode_tolerance_table(orc, name):
     try:
         for f32 in (False, True):
             gpu.set_storage_precision(f32)
-            orc.set_w_storage_f32(f32)
+            orc.set_w_storage_f32(2 if f32 else 0)
             out = _phases(orc, gpu, sc, spec.f0, 1e-4)
-            # blocks: V, U, gradient are never rounded; W to one float ulp
+            # blocks: V, U, gradient are never rounded
             assert rel_err(out["V_g"], out["V_o"]) < 1e-12 and rel_err(out["U_g"], out["U_o"]) < 1e-12
-            assert rel_err(out["W_g"], out["W_o"]) < (2.5e-7 if f32 else 1e-12)
+            dW = np.abs(out["W_g"] - out["W_o"]) / np.abs(out["W_o"]).max()
+            assert dW.max() < (1.3e-7 if f32 else 1e-12)
+            assert np.quantile(dW, 0.999) < 1e-12         # identically rounded factors but for rare boundary cases
             red = _reduced_index(sc.M)
             keep = red >= 0
-            assert rel_err(out["S_g"][np.ix_(keep, keep)], out["S_o"]) < (6e-7 if f32 else 1e-10)
+            assert rel_err(out["S_g"][np.ix_(keep, keep)], out["S_o"]) < (1e-9 if f32 else 1e-10)
             rc_o, rep_o, so, ok, rep, sg = _end_to_end(orc, gpu, sc, spec.f0, allowed=1e-9, max_factor=1e6, max_iterations=6)
             assert (rep.iterations, rep.attempts) == (rep_o.iterations, rep_o.attempts)
-            assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-5 if f32 else 1e-6)
+            assert rep.err_final == pytest.approx(rep_o.err_final, rel=1e-6)
             res[f32] = (out["S_g"].copy(), out["corr_g"].copy(), rep.err_final, out["W_g"].copy())
     finally:
-        orc.set_w_storage_f32(False)
+        orc.set_w_storage_f32(0)
         gpu.close()
     S64, c64, e64, W64 = res[False]
     S32, c32, e32, W32 = res[True]
