@@ -619,10 +619,10 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
 //   x = 2   forward-substitution workgroup: y_d = L_dd^-1 w_d as the tiles appear (flag Y(d)), w_t -= X_td y_d for the block's
 //           rows below.  (Inside the diagonal-block workgroup the 64 dependent steps took 4 - 8 us of a wave whose SIMD was
 //           streaming MFMAs.)
-//   x = 3..5  helper workgroups: the tiles (2, 2), (3, 2), (3, 3) of the diagonal block -- the ones behind the next panel -- take
-//           their rank-64 updates of the sub-steps d <= c - 2 here, from the published X tiles, and go back with flag G: the ONLY
-//           wait of the diagonal-block workgroup, for indices 3..5 of its own item, with a whole factorisation of slack.
-//   x >= 6  row workgroups: 64 rows each of the rows below the diagonal block (skyline rows, then the live border rows);
+//   x = 3   helper workgroup: the tiles (2, 2), (3, 2), (3, 3) of the diagonal block -- the ones behind the next panel -- take
+//           their rank-64 updates of the sub-steps d <= c - 2 here, from the published X tiles, and go back with flags G: the ONLY
+//           wait of the diagonal-block workgroup, for index 3 of its own item, with a whole factorisation of slack.
+//   x >= 4  row workgroups: 64 rows each of the rows below the diagonal block (skyline rows, then the live border rows);
 //           per sub-step: wait for F(d), sweep against L_dd, update w with y_(d-1), update the tiles (., d + 1 .. 3) with the
 //           published X_td.  One-way consumers: nothing waits for them inside the launch.
 // Hand-offs follow the guide's recipe (cdna_hip_programming.md, Guideline 16 R1): payload stored write-through (sc1
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void k_upd64(const CholBatch B, const CholStep
 // the launch that set it (the host counts launches per stream), so nothing is ever reset.  Every spin is bounded: a timeout
 // sets bit 8 of *info and the workgroup carries on (wrong numbers, flagged; the host repeats the solve with the unfused
 // kernels).  Deadlock: dispatch is in order of the linear workgroup index per XCD; every workgroup but index 0 waits only
-// for index 0 of its item, index 0 only for indices 3..5, which wait only for index 0: whenever the lowest unfinished
+// for index 0 of its item, index 0 only for index 3, which waits only for index 0: whenever the lowest unfinished
 // workgroup of an item is resident, the ones it can wait for are resident or first in line; the host keeps a launch within
 // 256 workgroups.
 // Arithmetic: potrf64 as in k_panel; the block's own rows are eliminated in the unscaled (L D L^T) form of potrf64 instead of
@@ -1209,17 +1209,16 @@ __global__ __launch_bounds__(STP_THREADS) void k_step256(const CholBatch B, cons
         }
         return;
     }
-    if (role >= 3 && role < 6) { // ---- helper workgroups: the tiles of the diagonal block behind the next panel.  Helper k owns
-        // tile (t, c) = (2, 2), (3, 2), (3, 3) and applies C -= X_td X_cd^T for the sub-steps d <= c - 2 (the update of
-        // sub-step c - 1 is the diagonal-block workgroup's: by then the tile is the next panel); one tile of MFMA work each,
-        // with a whole factorisation of slack, then flag G(k)
-        const int hk = role - 3, t = hk == 0 ? 2 : 3, c = hk == 2 ? 3 : 2;
+    if (role == 3) { // ---- helper workgroup: the tiles of the diagonal block behind the next panel, (t, c) = (2, 2), (3, 2),
+        // (3, 3).  Tile (t, c) takes C -= X_td X_cd^T for the sub-steps d <= c - 2 here (the update of sub-step c - 1 is the
+        // diagonal-block workgroup's: by then the tile is the next panel); a tile of MFMA work each, with a whole
+        // factorisation of slack, then flag G(k).  (One workgroup for the three tiles: a launch's workgroup count decides
+        // whether the two solves of a speculative pair fit the chip side by side.)
         const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
         const int sr = wave >> 1, sc = (wave & 1) * 32; // a wave takes a 16 x 32 strip
         double* Ablk = A + k0 * ld + k0;
-        double* pc0 = Ablk + (int64_t)(t * NB + 16 * sr + lk) * ld + c * NB + sc + lr;
-        for (int d = 0; d + 2 <= c; ++d) {
-            st_wait(fl, 1u << ST_F(d), epoch, info);
+        auto update = [&](int t, int c, int d) {
+            double* pc0 = Ablk + (int64_t)(t * NB + 16 * sr + lk) * ld + c * NB + sc + lr;
             double cv[2][4];
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -1236,16 +1235,28 @@ __global__ __launch_bounds__(STP_THREADS) void k_step256(const CholBatch B, cons
                 for (int reg = 0; reg < 4; ++reg) st_store(pc0 + (int64_t)(4 * reg) * ld + n * 16, cv[n][reg] - acc[n][reg]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads(); // (every wave has drained its stores; the LDS tiles are free)
-        }
-        if (tid == 0) __hip_atomic_store(fl + ST_G(hk), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        st_wait(fl, 1u << ST_F(0), epoch, info);
+        update(2, 2, 0);
+        if (tid == 0) __hip_atomic_store(fl + ST_G(0), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        update(3, 2, 0);
+        if (tid == 0) __hip_atomic_store(fl + ST_G(1), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        update(3, 3, 0);
+        st_wait(fl, 1u << ST_F(1), epoch, info);
+        update(3, 3, 1);
+        if (tid == 0) __hip_atomic_store(fl + ST_G(2), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    // (row workgroups of 128 rows -- two groups of 64, all eight waves multiplying -- were measured: a first-level launch
+    // then has 128 instead of 192 workgroups and the two solves of a speculative pair fit the chip side by side, but a row
+    // workgroup's sub-step (sweep + twice the MFMA work) then takes as long as the diagonal block's and the launch tail grows:
+    // solve 0.921 against 0.847 ms, pairs unchanged at 1.93 ms)
     // ---- row workgroups
     int64_t r0;
     {
         int64_t n1 = (row_end - (k0 + NBO)) / NB;
         if (n1 < 0) n1 = 0;
-        const int64_t r2_begin = r2b.v[z], n2 = (r2e.v[z] - r2_begin) / NB, ridx = role - 6;
+        const int64_t r2_begin = r2b.v[z], n2 = (r2e.v[z] - r2_begin) / NB, ridx = role - 4;
         if (ridx >= n1 + n2) return;
         r0 = ridx < n1 ? k0 + NBO + ridx * NB : r2_begin + (ridx - n1) * NB;
     }
@@ -1740,11 +1751,11 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
             if (n1 < 0) n1 = 0;
             row_wgs = std::max(row_wgs, n1 + (r2e.v[i] - r2b.v[i]) / NB);
         }
-        const bool fused = sync && sync->flags && sync->fused && (6 + row_wgs) * n <= 256;
+        const bool fused = sync && sync->flags && sync->fused && (4 + row_wgs) * n <= 256;
         if (fused) {
             ++sync->epoch;
             if (sync->epoch == 0) ++sync->epoch; // the flag words start at 0
-            LAUNCH(k_step256, dim3((unsigned)(6 + row_wgs), 1, (unsigned)n), dim3(STP_THREADS), 0, s, B, st, r2b, r2e, K, sync->flags,
+            LAUNCH(k_step256, dim3((unsigned)(4 + row_wgs), 1, (unsigned)n), dim3(STP_THREADS), 0, s, B, st, r2b, r2e, K, sync->flags,
                    sync->epoch, d_info);
         }
         for (int jsub = 0; jsub < NBO / NB && !fused; ++jsub) {
