@@ -1191,6 +1191,61 @@ static int upload_scene_impl(srk_ba* h, double f0, int64_t N, const double* pts_
             i = j;
         }
     }
+    // A small scene (the dino set: 36 frames, 4983 points; the point sets of the multi-view-factorisation calls) has a few
+    // dozen full-length runs: a few dozen workgroups on 256 CUs, each staging up to 128 landmarks four at a time -- the sum
+    // takes as long as one workgroup's 32 rounds (config 1: 114 us for 16 k observations).  Such runs are cut into `split`
+    // equal parts over the SAME frame set (slots and masks stay as they are; a cut that left a remainder to merge with the
+    // next frame list made ragged and wider runs: measured, worse).  What stops the cut: every part flushes the whole tile
+    // triangle of its frame set, and the parts of one round of workgroups flush together -- the fp64 atomics of a burst
+    // drain at ~0.5 TB/s (100 frames x 5000 points, 20-frame tracks: 74 / 72 / 78 / 96 / 155 us with 1 / 2 / 3 / 4 / 8
+    // parts; config 1, 4-frame tracks: 114 / 68 / 57 / 49 us with 1 / 2 / 3 / 4 parts, `tools/run_len_probe.py`) -- and a
+    // second round of workgroups.  The model below is that shape: a double round of eight landmarks ~5.5 us, 2 KB a tile.
+    {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        auto cost = [&](int split, int64_t* n_parts) {
+            double worst = 0, tiles = 0;
+            int64_t parts = 0;
+            for (size_t r = 0; r < grp_first.size(); ++r) {
+                const int64_t nfu = std::abs(grp_nf[r]), nt = (10 * nfu + 15) / 16, len = (grp_count[r] + split - 1) / split;
+                const int64_t k = std::min<int64_t>(split, (grp_count[r] + len - 1) / len);
+                parts += k;
+                tiles += (double)(k * nt * (nt + 1) / 2);
+                worst = std::max(worst, 4.5 + 5.5 * (double)((len + 7) / 8));
+            }
+            if (n_parts) *n_parts = parts;
+            return worst * (double)((parts + cus - 1) / cus) + tiles * 2048.0 / 0.5e6; // us
+        };
+        int split = 1;
+        if (!grp_first.empty() && (int)grp_first.size() < cus) {
+            double best = cost(1, nullptr);
+            for (int sp = 2; sp <= 8; ++sp) {
+                const double c = cost(sp, nullptr);
+                if (c < 0.9 * best) best = c, split = sp;
+            }
+        }
+#ifdef SRK_DEV
+        if (const char* e = getenv("SRK_SCHUR_RUN_SPLIT")) split = std::max(1, std::min(16, atoi(e))); // development: fixed cut
+#endif
+        if (split > 1) {
+            std::vector<int32_t> f2, c2, n2, fr2;
+            for (size_t r = 0; r < grp_first.size(); ++r) {
+                const int64_t len = (grp_count[r] + split - 1) / split;
+                for (int64_t a = 0; a < grp_count[r]; a += len) {
+                    f2.push_back(grp_first[r] + (int32_t)a);
+                    c2.push_back((int32_t)std::min<int64_t>(len, grp_count[r] - a));
+                    n2.push_back(grp_nf[r]);
+                    fr2.insert(fr2.end(), grp_frames.begin() + (ptrdiff_t)(r * SRK_GRP_MAXNF_HOST), grp_frames.begin() + (ptrdiff_t)((r + 1) * SRK_GRP_MAXNF_HOST));
+                    if (a > 0) {
+                        if (std::abs(grp_nf[r]) > SRK_GRP_NF1_HOST) ++n_wide;
+                        else if (std::abs(grp_nf[r]) > SRK_WS_NF_HOST) ++n_mid;
+                    }
+                }
+            }
+            grp_first.swap(f2); grp_count.swap(c2); grp_nf.swap(n2); grp_frames.swap(fr2);
+        }
+    }
     // Long tracks (> SRK_GRP_MAXNF_HOST frames; every track of the demos' all-visible scenes): runs of consecutive
     // candidates over the union of their frame lists (<= SRK_LONG_MAXNF_HOST frames), cut into blocks of 8 frames; one
     // work item per pair of blocks (k_schur_long).  A track over more frames than a run holds keeps the per-landmark kernel.
@@ -2060,7 +2115,7 @@ static void launch_solve(srk_ba* h, SrkSolveProf* prof)
                                P<int64_t>(h->env_col), P<int>(h->A->info), prof, &h->A->sync);
     else
         srk_chol_solve(h->stream, d.ld, P<double>(h->A->S), P<double>(h->A->rhs), P<double>(h->A->wy), P<double>(h->A->dc),
-                       P<int>(h->A->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->A->dinv), prof, &h->A->sync);
+                       P<int>(h->A->info), h->row_end_h.data(), h->col_begin_h.data(), P<double>(h->A->dinv), prof, &h->A->sync, 10 * (int64_t)d.M);
 }
 
 static int phase_solve(srk_ba* h, bool profile)
@@ -3161,7 +3216,7 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
     sync.flags = P<unsigned>(dflags);
     sync.fused = h->chol_fused;
     srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr, nullptr,
-                   P<double>(ddinv), nullptr, &sync);
+                   P<double>(ddinv), nullptr, &sync, n);
     HIPCHK(h, hipEventRecord(h->ev[15], s));
     HIPCHK(h, hipGetLastError());
     int info = 0;
@@ -3176,7 +3231,7 @@ int srk_ba_dense_spd_solve(srk_ba* h, int64_t n, const double* A, const double* 
         HIPCHK(h, hipMemcpyAsync(dw.p, bp.data(), bp.size() * 8, hipMemcpyHostToDevice, s));
         HIPCHK(h, hipMemsetAsync(dinfo.p, 0, 4, s));
         srk_chol_solve(s, ld, P<double>(dA), P<double>(dw), P<double>(dy), P<double>(dx), P<int>(dinfo), nullptr, nullptr,
-                       P<double>(ddinv), nullptr, &sync);
+                       P<double>(ddinv), nullptr, &sync, n);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(xs.data(), dx.p, xs.size() * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(&info, dinfo.p, 4, hipMemcpyDeviceToHost, s));

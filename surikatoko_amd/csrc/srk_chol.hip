@@ -267,6 +267,7 @@ struct CholItem {
 };
 struct CholBatch { CholItem it[SRK_MAX_CHUNKS]; };
 struct CholStep { int64_t v[SRK_MAX_CHUNKS]; }; // one per-launch value per item; < 0 = item takes no part
+struct CholSub { unsigned char v[SRK_MAX_CHUNKS]; }; // k_step256: an item's sub-steps on real columns (1 .. 4)
 // host side of an item: its skylines (may be NULL) and which of its border rows are structurally zero when.  The border
 // rows [r2_begin, r2_end) of a chunk are [separator above | separator below], r2_split between them.  A chunk without a
 // separator above (the first one) never needs the first part; the rows of the separator below stay zero until the
@@ -278,6 +279,8 @@ struct CholHostItem {
     const int64_t* col_begin;
     int64_t r2_split = 0, bot_first_col = 0;
     bool has_top = true, has_bot = true;
+    // columns from n_real on are padding: an identity diagonal, zeros elsewhere, which no update changes (a multiple of 64)
+    int64_t n_real = INT64_MAX;
 };
 
 // ---------------------------------------------------------------- inverse of a factored 64x64 diagonal tile
@@ -894,6 +897,7 @@ struct StepDiag { // what the sub-steps of the diagonal-block workgroup share
     int* info;
     int z;
     int64_t K;
+    int nsub;            // sub-steps on real columns (1 .. 4); the tiles of the others are padding: identity, zeros
     unsigned hu[3][SRK_STEP_MAXHOLD]; // this wave's hold units of the three updates (wave-uniform: scalar registers)
 };
 
@@ -938,7 +942,7 @@ template <int D, bool CHAIN> __device__ __forceinline__ void diag_update(const S
     // (opaque: nothing that depends on the thread index -- table entries, tile addresses -- is formed before this point, i.e.
     // while potrf64 needs every register)
     asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     double* const sm = S.sm;
     const int64_t ld = S.ld;
     const int64_t K = S.K; (void)K;
@@ -1023,7 +1027,6 @@ template <int D> __device__ __forceinline__ bool diag_chain_substep(const StepDi
     double (*Td)[LDSP] = reinterpret_cast<double (*)[LDSP]>(sm + D * STP_TILE);
     double* sInv = sm + STP_INV;
     unsigned* sCnt = reinterpret_cast<unsigned*>(sm + STP_CNT);
-    const int64_t ld = S.ld;
     const int64_t K = S.K; (void)K;
     __builtin_amdgcn_s_setprio(3); // the chain's instructions before the passenger wave's of the same SIMD
     const bool bad = potrf64<true>(Td, sm + STP_COL, sm + STP_DIAG, sInv, sm + STP_F, sm + STP_RSQ);
@@ -1031,15 +1034,20 @@ template <int D> __device__ __forceinline__ bool diag_chain_substep(const StepDi
     if (bad && tid == 0) atomicOr(S.info, 1);
     SST(1 + 6 * D);
     if (D == 0 && diag_fault(S)) return false;
-    // (the publication of L_DD and the X_tD is diag_update's first step; the last sub-step has no update: here)
-    if (D == 3) {
-        diag_publish<3, 4>(S, tid);
+    // (the publication of L_DD and the X_tD is diag_update's first step; the last sub-step has no update: here.  The last
+    // sub-step on real columns ends the chain: the tiles behind it are padding -- an identity diagonal, zeros below, which
+    // the updates with the all-zero X rows of padding leave as they are -- so global memory already holds their L = I and
+    // X = 0, and their flags go up with this one's: a 360-variable system pays for six tile factorisations, not eight)
+    if (D == 3 || S.nsub == D + 1) {
+        diag_publish<D, 4>(S, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             const unsigned old = atomicAdd(&sCnt[D], 1u);
-            if (old == 3) __hip_atomic_store(S.fl + ST_F(D), S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 3)
+                for (int d = D; d < NBO / NB; ++d) __hip_atomic_store(S.fl + ST_F(d), S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         SST(2 + 6 * D);
+        return false;
     }
     return true;
 }
@@ -1047,9 +1055,9 @@ static __device__ __forceinline__ void diag_chain(const StepDiag& S)
 {
     if (!diag_chain_substep<0>(S)) return;
     diag_update<0, true>(S);
-    diag_chain_substep<1>(S);
+    if (!diag_chain_substep<1>(S)) return;
     diag_update<1, true>(S);
-    diag_chain_substep<2>(S);
+    if (!diag_chain_substep<2>(S)) return;
     diag_update<2, true>(S);
     diag_chain_substep<3>(S);
 }
@@ -1080,21 +1088,23 @@ template <int D> __device__ __forceinline__ bool diag_passenger_substep(const St
     lds_barrier();
     SST(1 + 6 * D);
     if (D == 0 && diag_fault(S)) return false;
+    if (S.nsub == D + 1) return false; // (the chain ends here: see diag_chain_substep)
     return true;
 }
 static __device__ __forceinline__ void diag_passengers(const StepDiag& S)
 {
     if (!diag_passenger_substep<0>(S)) return;
     diag_update<0, false>(S);
-    diag_passenger_substep<1>(S);
+    if (!diag_passenger_substep<1>(S)) return;
     diag_update<1, false>(S);
-    diag_passenger_substep<2>(S);
+    if (!diag_passenger_substep<2>(S)) return;
     diag_update<2, false>(S);
     // (no rows are left below tile (3, 3): these waves end here, and the last factorisation's barriers count four waves)
 }
 
 __global__ __launch_bounds__(STP_THREADS) void k_step256(const CholBatch B, const CholStep rend, const CholStep r2b, const CholStep r2e,
-                                                        int64_t K, unsigned* __restrict__ flags, unsigned epoch, int* __restrict__ info)
+                                                        int64_t K, unsigned* __restrict__ flags, unsigned epoch, int* __restrict__ info,
+                                                        const CholSub nsubs)
 {
     const int z = blockIdx.z;
     const int64_t row_end = rend.v[z];
@@ -1108,7 +1118,7 @@ __global__ __launch_bounds__(STP_THREADS) void k_step256(const CholBatch B, cons
     __shared__ __attribute__((aligned(16))) double sm[STP_LDS_DOUBLES];
     SST(0);
     if (role == 0) { // ---- the diagonal block
-        StepDiag S{ sm, A + k0 * ld + k0, ld, fl, epoch, info, z, K, {} };
+        StepDiag S{ sm, A + k0 * ld + k0, ld, fl, epoch, info, z, K, (int)nsubs.v[z], {} };
         {
             const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
@@ -1755,8 +1765,13 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
         if (fused) {
             ++sync->epoch;
             if (sync->epoch == 0) ++sync->epoch; // the flag words start at 0
+            CholSub nsubs;
+            for (int i = 0; i < SRK_MAX_CHUNKS; ++i) {
+                const int64_t real = i < n && H[i].n_real > k0 ? (std::min(H[i].n_real, k0 + NBO) - k0 + NB - 1) / NB : NBO / NB;
+                nsubs.v[i] = (unsigned char)std::max<int64_t>(1, std::min<int64_t>(NBO / NB, real));
+            }
             LAUNCH(k_step256, dim3((unsigned)(4 + row_wgs), 1, (unsigned)n), dim3(STP_THREADS), 0, s, B, st, r2b, r2e, K, sync->flags,
-                   sync->epoch, d_info);
+                   sync->epoch, d_info, nsubs);
         }
         for (int jsub = 0; jsub < NBO / NB && !fused; ++jsub) {
             const int64_t d = K * (NBO / NB) + jsub;
@@ -1839,14 +1854,17 @@ static void chol_bwd(hipStream_t s, const CholBatch& B, int n, const CholHostIte
 // row_end[K] (host, one per outer panel, multiple of 128): rows >= row_end[K] have no non-zero in the panel's
 // columns and are skipped; NULL = dense.  col_begin[d64] (host, per 64-tile, may be NULL): first column with a
 // non-zero in tile row d64.  dinv: scratch, (ld / 64) * 64 * 64 doubles (inverses of the diagonal tiles).
+// n_real: rows and columns from there on are padding (identity diagonal, zero right-hand side); 0 = none
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
-                    const int64_t* row_end, const int64_t* col_begin, double* dinv, SrkSolveProf* prof, SrkCholSync* sync)
+                    const int64_t* row_end, const int64_t* col_begin, double* dinv, SrkSolveProf* prof, SrkCholSync* sync,
+                    int64_t n_real)
 {
     CholBatch B{};
     B.it[0] = CholItem{ A, w, y, x, dinv, ld, ld, ld, ld };
     CholHostItem H;
     H.row_end = row_end;
     H.col_begin = col_begin;
+    if (n_real > 0 && n_real < ld) H.n_real = (n_real + NB - 1) / NB * NB;
     chol_factor(s, B, 1, &H, d_info, prof, sync);
     chol_bwd(s, B, 1, &H, prof, d_info); // every variable is written by a k_bwd256 step, which checks it
 }

@@ -187,7 +187,8 @@ struct SrkCholSync {
 // row_end / col_begin: optional host arrays describing the skyline of A (see srk_chol.hip); NULL = dense.
 void srk_chol_solve(hipStream_t s, int64_t ld, double* A, double* w, double* y, double* x, int* d_info,
                     const int64_t* row_end, const int64_t* col_begin, double* dinv /* (ld / 64) * 4096 doubles */,
-                    struct SrkSolveProf* prof /* may be NULL */, struct SrkCholSync* sync /* NULL: unfused kernels */);
+                    struct SrkSolveProf* prof /* may be NULL */, struct SrkCholSync* sync /* NULL: unfused kernels */,
+                    int64_t n_real = 0 /* > 0: rows / columns from there on are padding (identity diagonal, zero rhs) */);
 
 // ---- chunked (bordered block-diagonal) solve of a banded reduced camera system (srk_chol.hip) ----
 #include <vector>
