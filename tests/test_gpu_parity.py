@@ -1268,10 +1268,11 @@ def test_fused_outer_step_is_reproducible_and_agrees_with_the_panel_sequence_den
     block for all four sub-steps and hands L and X tiles one way to row workgroups) against the k_panel / k_upd64 launch
     sequence it replaces.  Same factorisation, but the block's own rows are eliminated in potrf64's unscaled form (round 4), so
     the two agree to rounding; the fused solve must be IDENTICAL from run to run (no atomics, fixed summation order; repeated,
-    so that a stale read of a handed-off tile would have several chances to show).  Dense systems of one to five outer steps."""
+    so that a stale read of a handed-off tile would have several chances to show).  Dense systems of one to five outer steps;
+    the last step's chain ends at the last tile with real columns (1, 2, 3 or 4 sub-steps: 300, 360, 420, 200 / 256)."""
     rng = np.random.RandomState(5)
     try:
-        for n in (200, 256, 300, 777, 1280):
+        for n in (200, 256, 300, 360, 420, 777, 1280):
             A = rng.randn(n, n)
             A = A @ A.T + n * np.eye(n) + np.diag(np.arange(n) * 0.37)
             b = rng.randn(n)
