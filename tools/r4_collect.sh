@@ -15,6 +15,7 @@ python bench.py --store-f32 --steps 10 --warmup 2 --no-cpu-baseline --no-one-cal
 python bench.py --deterministic --steps 20 --warmup 5 --no-cpu-baseline --no-one-call --no-dense-probe > gpurun_out/r4/bench_C3_deterministic.json 2> gpurun_out/r4/bench_C3_deterministic.err
 python bench.py --config C2_all_visible --steps 5 --warmup 1 --no-cpu-baseline --no-one-call --no-dense-probe > gpurun_out/r4/bench_C2_all_visible.json 2> gpurun_out/r4/bench_C2_all_visible.err
 python tools/dbg_long_tracks.py > gpurun_out/r4/long_tracks.txt 2>&1
+SRK_BA_LIBRARY=$PWD/surikatoko_amd/libsrk_ba_dev.so python tools/run_len_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4/run_len_probe.txt
 timeout -k 10 300 bash tools/step_stamps.sh > gpurun_out/r4/step_stamps.txt 2>&1
 for f in gpurun_out/r4/bench_*.json; do python - "$f" <<'PY'
 import json,sys

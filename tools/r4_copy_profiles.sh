@@ -18,5 +18,6 @@ cp gpurun_out/r4/pmc_C3.txt $P/pmc_C3_1kcam_100kpt.txt
 cp gpurun_out/r4/bench_C3_deterministic.json $P/bench_C3_deterministic.json
 cp gpurun_out/r4/bench_C2_all_visible.json $P/bench_C2_all_visible.json
 grep -v amdgpu.ids gpurun_out/r4/long_tracks.txt > $P/long_tracks.txt
+cp gpurun_out/r4/run_len_probe.txt $P/run_len_probe.txt
 grep -A12 "^k_step256" gpurun_out/r4/step_stamps.txt > $P/step_stamps.txt
 ls -la $P
