@@ -1807,7 +1807,23 @@ static void chol_factor(hipStream_t s, const CholBatch& B, int n, const CholHost
         if (timed) hipEventRecord(prof->ev[2 * prof->n], s);
         int n_live = 0;
         for (int i = 0; i < n; ++i) n_live += st.v[i] >= 0 ? 1 : 0;
-        if (T > 0 && T <= 4 && (int64_t)n_live * (2 * T) * (2 * T + 1) / 2 <= 320) { // a few small blocks: 32x32 tiles, 16x the workgroups
+        // small blocks (T <= 4: at most 512 rows): 32x32 tiles, 16x the workgroups.  (Round 3 took this kernel for up to 320
+        // pairs of 64 x 64 tiles in a launch; round 4: for every such launch -- k_trail64 is latency-bound at the one to five
+        // workgroups a CU these launches have: C3's first level, 16 and 9 chunks of 36 pairs, 45.8 + 31.9 us against ~37 + 23
+        // (solve phase 0.859 -> 0.837 ms), C5's, 32 chunks, 2.065 -> 2.02 ms)
+        static const int64_t trail32_max = [] {
+#ifdef SRK_DEV
+            if (const char* e = getenv("SRK_TRAIL32_MAX")) return (int64_t)atoll(e); // development: A/B runs
+#endif
+            return (int64_t)1 << 40;
+        }();
+        static const int64_t trail32_t = [] {
+#ifdef SRK_DEV
+            if (const char* e = getenv("SRK_TRAIL32_T")) return (int64_t)atoll(e);
+#endif
+            return (int64_t)4;
+        }();
+        if (T > 0 && T <= trail32_t && (int64_t)n_live * (2 * T) * (2 * T + 1) / 2 <= trail32_max) {
             const int64_t T32 = 4 * T;
             LAUNCH(k_trail32, dim3((unsigned)(T32 * (T32 + 1) / 2), 1, (unsigned)n), dim3(256), 0, s, B, st, r2b, r2e, k0,
                                c_first);
